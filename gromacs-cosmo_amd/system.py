@@ -1,0 +1,211 @@
+"""Synthetic workloads of BASELINE.json and the interaction constants the reference's
+init_interaction_const (mdlib/forcerec.c:1976-2079) would hand to the kernels.
+
+Everything here is deterministic and self-contained (no file outside the package):
+the water boxes tile the 216-molecule SPC box shipped as data/spc216.npz.
+"""
+import math
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+ONE_4PI_EPS0 = 332.0636930 * 4.184 * 0.1   # legacyheaders/physics.h:82-83 = 138.935485
+
+# OPLS-AA SPC / SPC/E: share/top/oplsaa.ff/ffnonbonded.itp:127-128, spc.itp:7-9, spce.itp:7-9
+SIGMA_OW, EPS_OW = 0.316557, 0.650194
+Q_SPC = (-0.82, 0.41, 0.41)
+Q_SPCE = (-0.8476, 0.4238, 0.4238)
+
+
+@dataclass
+class System:
+    """Topology + coordinates in caller (molecule) order."""
+    x: np.ndarray            # [n,3] float32, inside the box
+    box: np.ndarray          # [3]
+    type: np.ndarray         # [n] int32, 0..ntype-1 (without the dummy type)
+    q: np.ndarray            # [n] float32
+    ntype: int               # number of real types; the list format adds one dummy type
+    c6: np.ndarray           # [ntype,ntype] C6
+    c12: np.ndarray          # [ntype,ntype] C12
+    excl_index: np.ndarray   # CSR exclusions, caller numbering (t_blocka)
+    excl_a: np.ndarray
+    name: str = ""
+
+    @property
+    def natoms(self):
+        return len(self.x)
+
+    def nbfp(self):
+        """6*C6 / 12*C12 table including the zero dummy type: nbnxn_atomdata.c:561,611-617,636-638."""
+        nt = self.ntype + 1
+        t = np.zeros((nt, nt, 2), dtype=np.float32)
+        t[:self.ntype, :self.ntype, 0] = 6.0 * self.c6
+        t[:self.ntype, :self.ntype, 1] = 12.0 * self.c12
+        return t
+
+
+@dataclass
+class InteractionParams:
+    """The scalars of interaction_const_t this path reads (types/interaction_const.h:68-130)."""
+    el_type: int
+    rcoulomb: float
+    rvdw: float
+    rlist: float
+    epsfac: float = ONE_4PI_EPS0
+    epsilon_r: float = 1.0
+    epsilon_rf: float = 0.0
+    k_rf: float = 0.0
+    c_rf: float = 0.0
+    ewaldcoeff_q: float = 0.0
+    sh_ewald: float = 0.0
+    disp_cpot: float = 0.0
+    rep_cpot: float = 0.0
+
+    def to_struct(self):
+        ic = abi.InteractionConst()
+        ic.vdwtype = abi.VDW_CUT
+        ic.vdw_modifier = abi.MOD_POTSHIFT
+        ic.rvdw = self.rvdw
+        ic.dispersion_shift.cpot = self.disp_cpot
+        ic.repulsion_shift.cpot = self.rep_cpot
+        ic.sh_invrc6 = -self.disp_cpot
+        ic.eeltype = abi.EEL_RF if self.el_type == abi.EL_RF else abi.EEL_PME
+        ic.coulomb_modifier = abi.MOD_POTSHIFT
+        ic.rcoulomb = self.rcoulomb
+        ic.rlist = self.rlist
+        ic.rlistlong = self.rlist
+        ic.ewaldcoeff_q = self.ewaldcoeff_q
+        ic.sh_ewald = self.sh_ewald
+        ic.epsilon_r = self.epsilon_r
+        ic.epsfac = self.epsfac
+        ic.epsilon_rf = self.epsilon_rf
+        ic.k_rf = self.k_rf
+        ic.c_rf = self.c_rf
+        return ic
+
+
+def calc_ewaldcoeff_q(rc, rtol):
+    """gmxlib/ewald_util.c:55-84: bisection on erfc(beta*rc) = rtol."""
+    x, i = 5.0, 0
+    while True:
+        i += 1
+        x *= 2
+        if math.erfc(x * rc) <= rtol:
+            break
+    lo, hi = 0.0, x
+    for _ in range(i + 60):
+        x = 0.5 * (lo + hi)
+        if math.erfc(x * rc) > rtol:
+            lo = x
+        else:
+            hi = x
+    return x
+
+
+def reaction_field(rc, rlist=None, epsilon_rf=78.0, epsilon_r=1.0):
+    """calc_rffac (mdlib/rf_util.c:205-245, kappa = 0) + potential-shift constants
+    (forcerec.c:2005-2011: cpot = -rc^-6 / -rc^-12)."""
+    if epsilon_rf == 0:
+        k_rf = 1.0 / (2 * rc ** 3)
+    else:
+        k_rf = (epsilon_rf - epsilon_r) / ((2 * epsilon_rf + epsilon_r) * rc ** 3)
+    c_rf = 1.0 / rc + k_rf * rc * rc
+    return InteractionParams(el_type=abi.EL_RF, rcoulomb=rc, rvdw=rc, rlist=rlist or rc,
+                             epsfac=ONE_4PI_EPS0 / epsilon_r, epsilon_r=epsilon_r, epsilon_rf=epsilon_rf,
+                             k_rf=k_rf, c_rf=c_rf, disp_cpot=-rc ** -6, rep_cpot=-rc ** -12)
+
+
+def ewald(rc, rlist=None, rtol=1e-5, epsilon_r=1.0):
+    """forcerec.c:2048-2053: beta from ewald_rtol; sh_ewald = erfc(beta*rc) exactly as the
+    reference computes it (no 1/rc factor in 5.0.4; identical at rc = 1 nm)."""
+    beta = calc_ewaldcoeff_q(rc, rtol)
+    return InteractionParams(el_type=abi.EL_EWALD_ANA, rcoulomb=rc, rvdw=rc, rlist=rlist or rc,
+                             epsfac=ONE_4PI_EPS0 / epsilon_r, epsilon_r=epsilon_r,
+                             ewaldcoeff_q=beta, sh_ewald=math.erfc(beta * rc),
+                             disp_cpot=-rc ** -6, rep_cpot=-rc ** -12)
+
+
+def _spc216():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "spc216.npz"))
+    return d["x"].astype(np.float64), d["box"].astype(np.float64)
+
+
+def water_box(nx, ny, nz, model="spc"):
+    """spc216 tiled nx*ny*nz times (the reference's `gmx genconf -nbox`): 648*nx*ny*nz atoms.
+    5x1x1 = 3,240 (config 1), 5x5x6 = 97,200 (configs 2/3), 13x13x14 = 1,533,168 (config 4)."""
+    x0, b0 = _spc216()
+    shifts = np.array([[i, j, k] for i in range(nx) for j in range(ny) for k in range(nz)], dtype=np.float64) * b0
+    x = (x0[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    box = b0 * np.array([nx, ny, nz])
+    x = x - np.floor(x / box) * box          # atom-wise put_atoms_in_box
+    x = x.astype(np.float32)
+    boxf = box.astype(np.float32)
+    x = np.where(x >= boxf, x - boxf, x)     # float rounding at the upper edge
+    n = len(x)
+    nmol = n // 3
+    qs = Q_SPC if model == "spc" else Q_SPCE
+    type_ = np.tile(np.array([0, 1, 1], dtype=np.int32), nmol)
+    q = np.tile(np.array(qs, dtype=np.float32), nmol)
+    c6 = np.zeros((2, 2))
+    c12 = np.zeros((2, 2))
+    c6[0, 0] = 4 * EPS_OW * SIGMA_OW ** 6
+    c12[0, 0] = 4 * EPS_OW * SIGMA_OW ** 12
+    # each atom excludes itself and the two others of its molecule (nrexcl 2 / [exclusions])
+    excl_index = np.arange(0, 3 * n + 1, 3, dtype=np.int32)
+    base = (np.arange(n, dtype=np.int32) // 3) * 3
+    excl_a = (base[:, None] + np.arange(3, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+    return System(x=x, box=boxf, type=type_, q=q, ntype=2, c6=c6, c12=c12,
+                  excl_index=excl_index, excl_a=excl_a, name=f"{model}216x{nx}x{ny}x{nz}")
+
+
+def lj_chain_mixture(natoms, ntype=8, seed=2026, density=100.0, chain_len=(12, 40)):
+    """Config-5-like synthetic system: an ntype-type LJ mixture of chain molecules with
+    1-2 and 1-3 exclusions and partial charges, on a jittered lattice (no reference fixture
+    exists for it).  Exclusion-dense, mixed LJ types."""
+    rng = np.random.default_rng(seed)
+    vol = natoms / density
+    L = vol ** (1.0 / 3.0)
+    m = int(math.ceil(natoms ** (1.0 / 3.0)))
+    a = L / m
+    idx = np.arange(m ** 3)[:natoms]
+    # serpentine order so that consecutive atoms (chain neighbours) are lattice neighbours
+    iz = idx // (m * m)
+    iy = (idx // m) % m
+    ix = idx % m
+    iy = np.where(iz % 2 == 1, m - 1 - iy, iy)
+    ix = np.where((iy + iz * m) % 2 == 1, m - 1 - ix, ix)
+    x = (np.stack([ix, iy, iz], axis=1) + 0.5) * a
+    x = x + rng.uniform(-0.12 * a, 0.12 * a, size=x.shape)
+    box = np.array([L, L, L], dtype=np.float32)
+    x = (x - np.floor(x / L) * L).astype(np.float32)
+    x = np.where(x >= box, x - box, x)
+    type_ = rng.integers(0, ntype, size=natoms).astype(np.int32)
+    sig = np.linspace(0.25, 0.36, ntype)
+    eps = np.linspace(0.2, 0.9, ntype)
+    s = 0.5 * (sig[:, None] + sig[None, :])
+    e = np.sqrt(eps[:, None] * eps[None, :])
+    c6 = 4 * e * s ** 6
+    c12 = 4 * e * s ** 12
+    q = rng.uniform(-0.4, 0.4, size=natoms)
+    # chains: neutralise each chain
+    lens = []
+    tot = 0
+    while tot < natoms:
+        l = int(rng.integers(chain_len[0], chain_len[1] + 1))
+        l = min(l, natoms - tot)
+        lens.append(l)
+        tot += l
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    ex_lists = []
+    for s0, l in zip(starts[:-1], lens):
+        q[s0:s0 + l] -= q[s0:s0 + l].mean()
+        for k in range(l):
+            lo, hi = max(0, k - 2), min(l - 1, k + 2)
+            ex_lists.append(np.arange(s0 + lo, s0 + hi + 1, dtype=np.int32))
+    excl_index = np.concatenate([[0], np.cumsum([len(e_) for e_ in ex_lists])]).astype(np.int32)
+    excl_a = np.concatenate(ex_lists).astype(np.int32)
+    return System(x=x, box=box, type=type_, q=q.astype(np.float32), ntype=ntype, c6=c6, c12=c12,
+                  excl_index=excl_index, excl_a=excl_a, name=f"ljchain{natoms}")

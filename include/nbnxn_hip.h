@@ -1,0 +1,423 @@
+/*
+ * nbnxn_hip.h -- C ABI of the MI355X (gfx950) Verlet cluster-pair nonbonded module.
+ *
+ * This is the drop-in boundary: a plain C interface (pointers, ints, floats) that the
+ * GROMACS 5.0.4 host code binds instead of its nbnxn_cuda_* module.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference tree,
+ * src/gromacs/...).  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions kept from the reference: real == float, gmx_bool == int, rvec == float[3],
+ * flags are GMX_FORCE_* bits (legacyheaders/types/force_flags.h:50-72), iloc/aloc are
+ * eintLocal/eintNonlocal and eatLocal/eatNonlocal (legacyheaders/types/nb_verlet.h:68-82).
+ *
+ * Error convention: the reference returns void and aborts through gmx_fatal
+ * (gmxlib/cuda_tools/cudautils.cuh:65-90).  Here every call returns 0 on success and a
+ * non-zero code on failure; by default a failure also prints the message and abort()s
+ * (gmx_fatal behaviour).  nbnxn_hip_set_abort_on_error(0) turns the abort off so that a
+ * host language runtime (the Python mirror, tests) can raise instead.
+ */
+#ifndef NBNXN_HIP_H
+#define NBNXN_HIP_H
+
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * Constants of the list format (mdlib/nbnxn_consts.h:50-83, legacyheaders/types/ishift.h)
+ * ---------------------------------------------------------------------------------- */
+#define NBX_CLUSTER_SIZE         8   /* atoms per i/j cluster (NBNXN_GPU_CLUSTER_SIZE)   */
+#define NBX_NCL_PER_SUPERCL      8   /* clusters per super-cluster (2x2x2)               */
+#define NBX_JGROUP_SIZE          4   /* j-clusters per cj4 entry                         */
+#define NBX_SHIFTS              45   /* SHIFTS                                           */
+#define NBX_CENTRAL             22   /* CENTRAL                                          */
+#define NBX_AVOID_SING_R2_INC   1.0e-12f
+
+/* GMX_FORCE_* bits that this module looks at (types/force_flags.h:66-68) */
+#define NBX_FORCE_VIRIAL        (1<<8)
+#define NBX_FORCE_ENERGY        (1<<9)
+
+/* interaction / atom locality (types/nb_verlet.h:68-82) */
+enum { NBX_LOCAL = 0, NBX_NONLOCAL = 1 };
+
+/* eeltype / vdwtype / modifier values this module accepts (types/enums.h:92-122) */
+enum { NBX_EEL_CUT = 0, NBX_EEL_RF = 1, NBX_EEL_GRF = 2, NBX_EEL_PME = 3, NBX_EEL_EWALD = 4 };
+enum { NBX_VDW_CUT = 0 };
+enum { NBX_MOD_POTSHIFT_VERLET = 0, NBX_MOD_POTSHIFT = 1, NBX_MOD_NONE = 2 };
+
+/* electrostatics flavour of the device kernel (nbnxn_cuda/nbnxn_cuda_types.h:80-82) */
+enum { NBX_EL_RF = 0, NBX_EL_EWALD_ANA = 1, NBX_EL_NR };
+
+/* ------------------------------------------------------------------------------------
+ * ABI structs.  Each is layout-identical to the named reference struct so that the
+ * reference host code can pass its own objects; oracle/abi_check.c static-asserts
+ * size and field offsets against the reference headers when /root/reference exists.
+ * ---------------------------------------------------------------------------------- */
+
+/* nbnxn_sci_t, types/nbnxn_pairlist.h:102-107 */
+typedef struct {
+    int sci;
+    int shift;
+    int cj4_ind_start;
+    int cj4_ind_end;
+} nbx_sci_t;
+
+/* nbnxn_im_ei_t / nbnxn_cj4_t, types/nbnxn_pairlist.h:109-117.  imei[w] belongs to lanes
+ * 32w..32w+31 of the wave (the reference's "warp" w). */
+typedef struct {
+    unsigned int imask;
+    int          excl_ind;
+} nbx_im_ei_t;
+
+typedef struct {
+    int         cj[4];
+    nbx_im_ei_t imei[2];
+} nbx_cj4_t;
+
+/* nbnxn_excl_t, types/nbnxn_pairlist.h:119-123 */
+typedef struct {
+    unsigned int pair[32];
+} nbx_excl_t;
+
+/* nbnxn_ci_t / nbnxn_cj_t (simple 4x4 list, only carried, never read here) :75-99 */
+typedef struct { int cj; unsigned int excl; } nbx_cj_t;
+typedef struct { int ci; int shift; int cj_ind_start; int cj_ind_end; } nbx_ci_t;
+
+typedef struct { int dummy[16]; } nbx_cache_protect_t;   /* gmx_cache_protect_t :50-52 */
+
+typedef void nbx_alloc_t(void **ptr, size_t nbytes);     /* nbnxn_alloc_t :61 */
+typedef void nbx_free_t(void *ptr);                      /* nbnxn_free_t  :66 */
+
+/* nbnxn_pairlist_t, types/nbnxn_pairlist.h:125-160 */
+typedef struct {
+    nbx_cache_protect_t cp0;
+    nbx_alloc_t        *alloc;
+    nbx_free_t         *free;
+    int                 bSimple;
+    int                 na_ci;
+    int                 na_cj;
+    int                 na_sc;
+    float               rlist;
+    int                 nci;
+    nbx_ci_t           *ci;
+    int                 ci_nalloc;
+    int                 nsci;
+    nbx_sci_t          *sci;
+    int                 sci_nalloc;
+    int                 ncj;
+    nbx_cj_t           *cj;
+    int                 cj_nalloc;
+    int                 ncj4;
+    nbx_cj4_t          *cj4;
+    int                 cj4_nalloc;
+    int                 nexcl;
+    nbx_excl_t         *excl;
+    int                 excl_nalloc;
+    int                 nci_tot;
+    void               *work;
+    nbx_cache_protect_t cp1;
+} nbx_pairlist_t;
+
+/* nbnxn_pairlist_set_t, types/nbnxn_pairlist.h:162-172 */
+typedef struct {
+    int              nnbl;
+    nbx_pairlist_t **nbl;
+    int              bCombined;
+    int              bSimple;
+    int              natpair_ljq;
+    int              natpair_lj;
+    int              natpair_q;
+    void           **nbl_fep;
+} nbx_pairlist_set_t;
+
+/* nbnxn_atomdata_output_t, types/nbnxn_pairlist.h:178-187 */
+typedef struct {
+    float *f;
+    float *fshift;
+    int    nV;
+    float *Vvdw;
+    float *Vc;
+    int    nVS;
+    float *VSvdw;
+    float *VSc;
+} nbx_atomdata_output_t;
+
+/* nbnxn_buffer_flags_t :212-216 */
+typedef struct {
+    int           nflag;
+    unsigned int *flag;
+    int           flag_nalloc;
+} nbx_buffer_flags_t;
+
+/* nbnxn_atomdata_t, types/nbnxn_pairlist.h:226-271.  For the GPU path the reference sets
+ * XFormat = nbatXYZQ (x is float4 xyzq, xstride 4), FFormat = nbatXYZ (fstride 3), nout 1
+ * (mdlib/nbnxn_atomdata.c:734-749). */
+typedef struct {
+    nbx_alloc_t           *alloc;
+    nbx_free_t            *free;
+    int                    ntype;
+    float                 *nbfp;
+    int                    comb_rule;
+    float                 *nbfp_comb;
+    float                 *nbfp_s4;
+    int                    natoms;
+    int                    natoms_local;
+    int                   *type;
+    float                 *lj_comb;
+    int                    XFormat;
+    int                    FFormat;
+    float                 *q;
+    int                    na_c;
+    int                    nenergrp;
+    int                    neg_2log;
+    int                   *energrp;
+    int                    bDynamicBox;
+    float                (*shift_vec)[3];
+    int                    xstride;
+    int                    fstride;
+    float                 *x;
+    float                 *simd_4xn_diagonal_j_minus_i;
+    float                 *simd_2xnn_diagonal_j_minus_i;
+    unsigned int          *simd_exclusion_filter1;
+    unsigned int          *simd_exclusion_filter2;
+    float                 *simd_interaction_array;
+    int                    nout;
+    nbx_atomdata_output_t *out;
+    int                    nalloc;
+    int                    bUseBufferFlags;
+    nbx_buffer_flags_t     buffer_flags;
+    int                    bUseTreeReduce;
+    void                  *syncStep;
+} nbx_atomdata_t;
+
+/* shift_consts_t / switch_consts_t / interaction_const_t, types/interaction_const.h:49-130 */
+typedef struct { float c2, c3, cpot; } nbx_shift_consts_t;
+typedef struct { float c3, c4, c5; } nbx_switch_consts_t;
+
+typedef struct {
+    int                 vdwtype;
+    int                 vdw_modifier;
+    float               rvdw;
+    float               rvdw_switch;
+    nbx_shift_consts_t  dispersion_shift;
+    nbx_shift_consts_t  repulsion_shift;
+    nbx_switch_consts_t vdw_switch;
+    float               sh_invrc6;
+    int                 eeltype;
+    int                 coulomb_modifier;
+    float               rcoulomb;
+    float               rlist;
+    float               rlistlong;
+    float               ewaldcoeff_q;
+    float               ewaldcoeff_lj;
+    int                 ljpme_comb_rule;
+    float               sh_ewald;
+    float               sh_lj_ewald;
+    float               epsilon_r;
+    float               epsfac;
+    float               epsilon_rf;
+    float               k_rf;
+    float               c_rf;
+    float               tabq_scale;
+    int                 tabq_size;
+    float              *tabq_coul_F;
+    float              *tabq_coul_V;
+    float              *tabq_coul_FDV0;
+    float              *tabq_vdw_F;
+    float              *tabq_vdw_V;
+    float              *tabq_vdw_FDV0;
+} nbx_interaction_const_t;
+
+/* nonbonded_verlet_group_t, types/nb_verlet.h:91-96 */
+typedef struct {
+    nbx_pairlist_set_t nbl_lists;
+    nbx_atomdata_t    *nbat;
+    int                kernel_type;
+    int                ewald_excl;
+} nbx_verlet_group_t;
+
+/* nbnxn_cuda_ktime / wallclock_gpu, types/nbnxn_cuda_types_ext.h:55-71 */
+typedef struct { double t; int c; } nbx_ktime_t;
+typedef struct {
+    nbx_ktime_t ktime[2][2];   /* [prune][energy], milliseconds and call count */
+    double      nb_h2d_t;
+    double      nb_d2h_t;
+    int         nb_c;
+    double      pl_h2d_t;
+    int         pl_h2d_c;
+} nbx_wallclock_gpu_t;
+
+/* opaque module handle; replaces nbnxn_cuda_ptr_t (types/nbnxn_cuda_types_ext.h:45) */
+typedef struct nbnxn_hip *nbnxn_hip_ptr_t;
+
+/* ------------------------------------------------------------------------------------
+ * Error handling
+ * ---------------------------------------------------------------------------------- */
+void        nbnxn_hip_set_abort_on_error(int abort_on_error);
+const char *nbnxn_hip_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Device selection; replaces detect_cuda_gpus / init_gpu / free_gpu /
+ * get_gpu_device_info_string (gmxlib/gpu_utils/gpu_utils.h:63-107).
+ * ---------------------------------------------------------------------------------- */
+int nbnxn_hip_detect_gpus(int *ngpu, char *err_str, int err_len);
+int nbnxn_hip_init_gpu(int device_id, char *result_str, int result_len);
+int nbnxn_hip_free_gpu(char *result_str, int result_len);
+int nbnxn_hip_get_current_gpu_device_id(void);
+int nbnxn_hip_get_gpu_device_info_string(char *s, int len, int device_id);
+
+/* pinned host memory; replaces pmalloc / pfree (gmxlib/cuda_tools/pmalloc_cuda.cu:45,91),
+ * the nbnxn_alloc_t / nbnxn_free_t hooks handed to nbnxn_init_pairlist_set and
+ * nbnxn_atomdata_init (mdlib/forcerec.c:2247-2262). */
+void nbnxn_hip_pmalloc(void **h_ptr, size_t nbytes);
+void nbnxn_hip_pfree(void *h_ptr);
+
+/* ------------------------------------------------------------------------------------
+ * Data management; one-to-one with legacyheaders/nbnxn_cuda_data_mgmt.h:59-139
+ * ---------------------------------------------------------------------------------- */
+
+/* nbnxn_cuda_init (nbnxn_cuda_data_mgmt.h:59): creates the handle on device device_id with
+ * one stream (local) or two (local + high-priority non-local).  The reference's
+ * gpu_info/gpu_opt/my_gpu_index triple only selects the device id, passed here directly. */
+int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocalAndNonlocal);
+
+/* nbnxn_cuda_init_const (:69): cut-offs, RF/Ewald constants, LJ table; picks the kernel
+ * flavour; clears the energy and shift-force outputs. */
+int nbnxn_hip_init_const(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic,
+                         const nbx_verlet_group_t *nbv_group);
+
+/* nbnxn_cuda_init_pairlist (:75): uploads sci/cj4/excl of a GPU-format list and arms the
+ * pruning kernel flavour for the next launch of that locality. */
+int nbnxn_hip_init_pairlist(nbnxn_hip_ptr_t nb, const nbx_pairlist_t *h_nblist, int iloc);
+
+/* nbnxn_cuda_init_atomdata (:81): (re)allocates xq/f/type for natoms, uploads types. */
+int nbnxn_hip_init_atomdata(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat);
+
+/* nbnxn_cuda_pme_loadbal_update_param (:86) */
+int nbnxn_hip_pme_loadbal_update_param(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic);
+
+/* nbnxn_cuda_upload_shiftvec (:91): uploads the 45 shift vectors if the box is dynamic or
+ * they were never uploaded. */
+int nbnxn_hip_upload_shiftvec(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat);
+
+/* nbnxn_cuda_clear_outputs (:96): zeroes f; zeroes fshift/energies if flags has VIRIAL. */
+int nbnxn_hip_clear_outputs(nbnxn_hip_ptr_t nb, int flags);
+
+/* nbnxn_cuda_free (:101) */
+int nbnxn_hip_free(nbnxn_hip_ptr_t nb);
+
+/* nbnxn_cuda_get_timings / _reset_timings (:105,116); NULL when timing is off. */
+nbx_wallclock_gpu_t *nbnxn_hip_get_timings(nbnxn_hip_ptr_t nb);
+int                  nbnxn_hip_reset_timings(nbnxn_hip_ptr_t nb);
+
+/* nbnxn_cuda_min_ci_balanced (:121): the pair-list split target (number of sci entries the
+ * list builder should aim for); tuned for 256 CUs x 4 SIMDs instead of 40 x #SM. */
+int nbnxn_hip_min_ci_balanced(nbnxn_hip_ptr_t nb);
+
+/* nbnxn_cuda_is_kernel_ewald_analytical (:132) */
+int nbnxn_hip_is_kernel_ewald_analytical(const nbnxn_hip_ptr_t nb);
+
+/* ------------------------------------------------------------------------------------
+ * Per-step calls; one-to-one with mdlib/nbnxn_cuda/nbnxn_cuda.h:64-86
+ * ---------------------------------------------------------------------------------- */
+
+/* nbnxn_cuda_launch_kernel (:64): async H2D of nbat->x for the locality, then the kernel. */
+int nbnxn_hip_launch_kernel(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags, int iloc);
+
+/* nbnxn_cuda_launch_cpyback (:72): async D2H of f (into nbat->out[0].f), and of
+ * fshift/energies on the local stream when flags has VIRIAL. */
+int nbnxn_hip_launch_cpyback(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags, int aloc);
+
+/* nbnxn_cuda_wait_gpu (:80): blocks until the locality's stream is idle; ADDS e_lj, e_el
+ * and fshift[45] into the caller's accumulators (local only); disarms pruning. */
+int nbnxn_hip_wait_gpu(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags, int aloc,
+                       float *e_lj, float *e_el, float (*fshift)[3]);
+
+/* ------------------------------------------------------------------------------------
+ * Flat variants (plain pointers and sizes) of the struct-taking calls above, for hosts
+ * that do not hold the GROMACS structs (the Python mirror, tests, bench).  Same semantics.
+ * ---------------------------------------------------------------------------------- */
+
+/* = nbnxn_hip_init_const.  nbfp is [ntype*ntype*2] (6*C6, 12*C12 pairs,
+ * mdlib/nbnxn_atomdata.c:611-617); el_type is NBX_EL_RF or NBX_EL_EWALD_ANA. */
+int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type,
+                              float rcoulomb, float rvdw, float rlist,
+                              float epsfac, float k_rf, float c_rf,
+                              float ewaldcoeff_q, float sh_ewald,
+                              float disp_cpot, float rep_cpot,
+                              int ntype, const float *nbfp);
+
+/* = nbnxn_hip_init_pairlist */
+int nbnxn_hip_init_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc, float rlist,
+                                 int nsci, const nbx_sci_t *sci,
+                                 int ncj4, const nbx_cj4_t *cj4,
+                                 int nexcl, const nbx_excl_t *excl, int nci_tot);
+
+/* = nbnxn_hip_init_atomdata */
+int nbnxn_hip_init_atomdata_flat(nbnxn_hip_ptr_t nb, int natoms, int natoms_local,
+                                 int ntype, const int *type);
+
+/* = nbnxn_hip_upload_shiftvec (always uploads) */
+int nbnxn_hip_upload_shiftvec_flat(nbnxn_hip_ptr_t nb, const float *shift_vec /* [45*3] */);
+
+/* = nbnxn_hip_launch_kernel: xq is the host float4 array [natoms*4]. */
+int nbnxn_hip_launch_kernel_flat(nbnxn_hip_ptr_t nb, const float *xq, int flags, int iloc);
+
+/* = nbnxn_hip_launch_cpyback: f is the host array [natoms*3]. */
+int nbnxn_hip_launch_cpyback_flat(nbnxn_hip_ptr_t nb, float *f, int flags, int aloc);
+
+/* = nbnxn_hip_wait_gpu */
+int nbnxn_hip_wait_gpu_flat(nbnxn_hip_ptr_t nb, int flags, int aloc,
+                            float *e_lj, float *e_el, float *fshift /* [45*3] */);
+
+/* ------------------------------------------------------------------------------------
+ * Resident-coordinate extension: x and f stay in HBM between steps, so the
+ * per-step PCIe round trip of launch_kernel/launch_cpyback disappears.  Used by bench.py
+ * (the timed region starts with inputs in HBM) and by the multi-GPU halo exchange, which
+ * hands these device pointers to RCCL send/recv.
+ * ---------------------------------------------------------------------------------- */
+
+/* device addresses of the xq (float4), f (float[3]) and atom-type arrays */
+int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, void **d_type);
+
+/* the HIP stream (hipStream_t) of a locality, as an opaque pointer */
+void *nbnxn_hip_get_stream(nbnxn_hip_ptr_t nb, int iloc);
+
+/* kernel only, no H2D: coordinates already resident. */
+int nbnxn_hip_launch_kernel_resident(nbnxn_hip_ptr_t nb, int flags, int iloc);
+
+/* device-side energy / shift-force outputs without the host accumulate of wait_gpu:
+ * copies e_lj, e_el, fshift[135] to host (synchronises the local stream). */
+int nbnxn_hip_read_outputs(nbnxn_hip_ptr_t nb, float *e_lj, float *e_el, float *fshift);
+
+/* bit-exact list verification (north_star: "uploaded once per list lifetime and verified
+ * bit-exact"): reads sci/cj4/excl back from HBM and compares with the host list; cj4.cj
+ * slots whose imask byte is 0 are padding and are ignored (SURVEY 8a trap 1).
+ * Returns 0 when identical, otherwise the number of differing words. */
+int nbnxn_hip_verify_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc,
+                                   int nsci, const nbx_sci_t *sci,
+                                   int ncj4, const nbx_cj4_t *cj4,
+                                   int nexcl, const nbx_excl_t *excl);
+
+/* reads the (possibly pruned) cj4 array back from HBM; for tests of the prune flavour. */
+int nbnxn_hip_download_cj4(nbnxn_hip_ptr_t nb, int iloc, int ncj4, nbx_cj4_t *cj4);
+
+/* last kernel duration of a locality in milliseconds from the module's HIP events
+ * (the wallclock_gpu_t source); <0 when no kernel was timed yet. */
+float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc);
+
+/* arms (1) or disarms (0) the pruning flavour for the next launch of a locality;
+ * the reference arms it in init_pairlist and disarms it in wait_gpu. */
+int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune);
+
+/* kernel tuning knob for benchmarking: 0 = default variant */
+int nbnxn_hip_set_kernel_variant(nbnxn_hip_ptr_t nb, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NBNXN_HIP_H */
