@@ -1,0 +1,834 @@
+// C-ABI layer of the MI355X nonbonded module: device data management and per-step calls
+// (include/nbnxn_hip.h).  Replaces mdlib/nbnxn_cuda/nbnxn_cuda_data_mgmt.cu and the host
+// part of nbnxn_cuda.cu; structure is our own: one handle, two HIP streams, plain
+// hipMalloc'd arrays with 20 % over-allocation, hipEvent timing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nbnxn_hip.h"
+#include "nbnxn_kernel.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+int                      g_abort_on_error = 1;
+
+// gmx_fatal equivalent (cudautils.cuh:65-90): message, then abort unless switched off
+int nbx_fail(const char *fmt, ...)
+{
+    char    buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (g_abort_on_error)
+    {
+        fprintf(stderr, "nbnxn_hip fatal error: %s\n", buf);
+        abort();
+    }
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) { return nbx_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T     *p     = nullptr;
+    size_t n     = 0;   // elements in use
+    size_t alloc = 0;   // elements allocated
+};
+
+// cu_realloc_buffered equivalent (cudautils.cu): grow with head-room, never shrink
+template <typename T>
+int dev_reserve(DevBuf<T> &b, size_t n, bool *realloced = nullptr)
+{
+    if (realloced) { *realloced = false; }
+    if (n > b.alloc)
+    {
+        if (b.p) { HIP_TRY(hipFree(b.p)); b.p = nullptr; }
+        const size_t na = n + n / 5 + 64;
+        HIP_TRY(hipMalloc((void **)&b.p, na * sizeof(T)));
+        b.alloc = na;
+        if (realloced) { *realloced = true; }
+    }
+    b.n = n;
+    return 0;
+}
+
+template <typename T>
+void dev_free(DevBuf<T> &b)
+{
+    if (b.p) { (void)hipFree(b.p); }
+    b.p = nullptr; b.n = b.alloc = 0;
+}
+
+struct PList {
+    DevBuf<nbx_sci_t>  sci;
+    DevBuf<nbx_cj4_t>  cj4;
+    DevBuf<nbx_excl_t> excl;
+    DevBuf<float>      partial;
+    int                nsci = 0, ncj4 = 0, nexcl = 0, nci_tot = 0;
+    float              rlist = 0;
+    bool               do_prune = false;
+};
+
+} // namespace
+
+struct nbnxn_hip {
+    int         device = 0;
+    bool        two_streams = false;
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t  misc_ops_done = nullptr, nonlocal_done = nullptr;
+    hipEvent_t  k_start[2] = {nullptr, nullptr}, k_stop[2] = {nullptr, nullptr};
+    hipEvent_t  h2d_start[2] = {nullptr, nullptr}, h2d_stop[2] = {nullptr, nullptr};
+    hipEvent_t  d2h_start[2] = {nullptr, nullptr}, d2h_stop[2] = {nullptr, nullptr};
+    bool        k_timed[2] = {false, false}, h2d_timed[2] = {false, false}, d2h_timed[2] = {false, false};
+    bool        last_ener[2] = {false, false}, last_prune[2] = {false, false};
+    bool        do_time = true;
+
+    // atom data
+    DevBuf<float4> xq;
+    DevBuf<float>  f;
+    DevBuf<int>    type;
+    float         *shift_vec = nullptr;   // 45*3
+    float         *fshift = nullptr;      // 45*3
+    float         *e_lj = nullptr, *e_el = nullptr;
+    int            natoms = 0, natoms_local = 0, ntype = 0;
+    bool           shift_vec_uploaded = false;
+
+    // parameters
+    DevBuf<float2> nbfp;
+    int            el_type = NBX_EL_RF;
+    float          rcoulomb = 0, rvdw = 0, rlist = 0;
+    float          epsfac = 0, k_rf = 0, c_rf = 0, beta = 0, sh_ewald = 0, disp_cpot = 0, rep_cpot = 0;
+    bool           have_const = false;
+
+    PList plist[2];
+
+    // pinned staging for the small outputs (nb_staging, nbnxn_cuda_types.h:104-110)
+    float *h_stage = nullptr;   // [0] e_lj, [1] e_el, [2..136] fshift
+
+    nbx_wallclock_gpu_t timings;
+    int                 variant = 0;
+};
+
+namespace {
+
+int check_handle(nbnxn_hip_ptr_t nb)
+{
+    if (!nb) { return nbx_fail("null nbnxn_hip handle"); }
+    return 0;
+}
+
+int check_loc(int loc)
+{
+    if (loc != NBX_LOCAL && loc != NBX_NONLOCAL)
+    {
+        return nbx_fail("Invalid locality passed (%d); valid here is only local (%d) or nonlocal (%d)", loc, NBX_LOCAL, NBX_NONLOCAL);
+    }
+    return 0;
+}
+
+// atom range of a locality (nbnxn_cuda.cu:311-321)
+void loc_range(const nbnxn_hip *nb, int loc, int *begin, int *len)
+{
+    if (loc == NBX_LOCAL) { *begin = 0; *len = nb->natoms_local; }
+    else { *begin = nb->natoms_local; *len = nb->natoms - nb->natoms_local; }
+}
+
+int set_params(nbnxn_hip *nb, int el_type, float rcoulomb, float rvdw, float rlist, float epsfac,
+               float k_rf, float c_rf, float beta, float sh_ewald, float disp_cpot, float rep_cpot)
+{
+    if (el_type != NBX_EL_RF && el_type != NBX_EL_EWALD_ANA) { return nbx_fail("unsupported electrostatics flavour %d", el_type); }
+    if (!(rcoulomb > 0)) { return nbx_fail("rcoulomb must be > 0"); }
+    if (rvdw != rcoulomb)
+    {
+        return nbx_fail("rvdw (%g) != rcoulomb (%g): the twin-range (VDW_CUTOFF_CHECK) flavours are not built yet", rvdw, rcoulomb);
+    }
+    if (el_type == NBX_EL_EWALD_ANA && beta * beta * rcoulomb * rcoulomb > 16.0f)
+    {
+        return nbx_fail("(ewaldcoeff_q*rcoulomb)^2 = %g exceeds the range (16) of the analytical Ewald fit", beta * beta * rcoulomb * rcoulomb);
+    }
+    nb->el_type = el_type;
+    nb->rcoulomb = rcoulomb; nb->rvdw = rvdw; nb->rlist = rlist;
+    nb->epsfac = epsfac; nb->k_rf = k_rf; nb->c_rf = c_rf;
+    nb->beta = beta; nb->sh_ewald = sh_ewald;
+    nb->disp_cpot = disp_cpot; nb->rep_cpot = rep_cpot;
+    nb->have_const = true;
+    return 0;
+}
+
+int upload_nbfp(nbnxn_hip *nb, int ntype, const float *nbfp)
+{
+    if (ntype <= 0 || !nbfp) { return nbx_fail("bad LJ table"); }
+    if (dev_reserve(nb->nbfp, (size_t)ntype * ntype)) { return 1; }
+    HIP_TRY(hipMemcpyAsync(nb->nbfp.p, nbfp, (size_t)ntype * ntype * sizeof(float2), hipMemcpyHostToDevice, nb->stream[0]));
+    HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    nb->ntype = ntype;
+    return 0;
+}
+
+int clear_e_fshift(nbnxn_hip *nb)
+{
+    HIP_TRY(hipMemsetAsync(nb->fshift, 0, NBX_SHIFTS * 3 * sizeof(float), nb->stream[0]));
+    HIP_TRY(hipMemsetAsync(nb->e_lj, 0, sizeof(float), nb->stream[0]));
+    HIP_TRY(hipMemsetAsync(nb->e_el, 0, sizeof(float), nb->stream[0]));
+    return 0;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { return 0; }
+    return ms;
+}
+
+int init_pairlist_impl(nbnxn_hip *nb, int iloc, float rlist, int nsci, const nbx_sci_t *sci,
+                       int ncj4, const nbx_cj4_t *cj4, int nexcl, const nbx_excl_t *excl, int nci_tot)
+{
+    if (check_loc(iloc)) { return 1; }
+    if (nsci < 0 || ncj4 < 0 || nexcl < 0) { return nbx_fail("negative list size"); }
+    if (nsci > 0 && (!sci || !cj4 || !excl || nexcl < 1)) { return nbx_fail("list arrays missing"); }
+    // host-side shape check before anything reaches a kernel: every index the kernel will
+    // follow must stay inside the uploaded arrays and the atom arrays
+    const int ncl = nb->natoms / NBX_CLUSTER_SIZE;
+    for (int s = 0; s < nsci; s++)
+    {
+        if (sci[s].cj4_ind_start < 0 || sci[s].cj4_ind_end < sci[s].cj4_ind_start || sci[s].cj4_ind_end > ncj4)
+        {
+            return nbx_fail("sci[%d] has cj4 range [%d,%d) outside [0,%d)", s, sci[s].cj4_ind_start, sci[s].cj4_ind_end, ncj4);
+        }
+        if (sci[s].shift < 0 || sci[s].shift >= NBX_SHIFTS) { return nbx_fail("sci[%d] has shift %d", s, sci[s].shift); }
+        if (sci[s].sci < 0 || (sci[s].sci + 1) * NBX_NCL_PER_SUPERCL > ncl)
+        {
+            return nbx_fail("sci[%d] = %d lies outside the %d atoms set by init_atomdata", s, sci[s].sci, nb->natoms);
+        }
+    }
+    for (int c = 0; c < ncj4; c++)
+    {
+        for (int w = 0; w < 2; w++)
+        {
+            if (cj4[c].imei[w].excl_ind < 0 || cj4[c].imei[w].excl_ind >= nexcl) { return nbx_fail("cj4[%d] has excl_ind %d outside [0,%d)", c, cj4[c].imei[w].excl_ind, nexcl); }
+        }
+        const unsigned m = cj4[c].imei[0].imask | cj4[c].imei[1].imask;
+        for (int jm = 0; jm < 4; jm++)
+        {
+            if (((m >> (8 * jm)) & 0xffu) && (cj4[c].cj[jm] < 0 || cj4[c].cj[jm] >= ncl))
+            {
+                return nbx_fail("cj4[%d].cj[%d] = %d lies outside the %d clusters set by init_atomdata", c, jm, cj4[c].cj[jm], ncl);
+            }
+        }
+    }
+    PList      &pl = nb->plist[iloc];
+    hipStream_t st = nb->stream[iloc];
+    if (dev_reserve(pl.sci, nsci) || dev_reserve(pl.cj4, ncj4) || dev_reserve(pl.excl, nexcl) ||
+        dev_reserve(pl.partial, (size_t)nsci * NBX_PARTIAL_STRIDE))
+    {
+        return 1;
+    }
+    hipEvent_t t0 = nb->h2d_start[iloc], t1 = nb->h2d_stop[iloc];
+    if (nb->do_time) { HIP_TRY(hipEventRecord(t0, st)); }
+    if (nsci > 0)
+    {
+        HIP_TRY(hipMemcpyAsync(pl.sci.p, sci, (size_t)nsci * sizeof(nbx_sci_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl.cj4.p, cj4, (size_t)ncj4 * sizeof(nbx_cj4_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl.excl.p, excl, (size_t)nexcl * sizeof(nbx_excl_t), hipMemcpyHostToDevice, st));
+    }
+    if (nb->do_time)
+    {
+        HIP_TRY(hipEventRecord(t1, st));
+        HIP_TRY(hipEventSynchronize(t1));
+        nb->timings.pl_h2d_t += elapsed(t0, t1);
+        if (iloc == NBX_LOCAL) { nb->timings.pl_h2d_c++; }
+    }
+    else
+    {
+        HIP_TRY(hipStreamSynchronize(st));   // the host arrays may be reused by the caller
+    }
+    pl.nsci = nsci; pl.ncj4 = ncj4; pl.nexcl = nexcl; pl.nci_tot = nci_tot; pl.rlist = rlist;
+    pl.do_prune = true;   // a fresh list gets pruned by its first kernel (nbnxn_cuda_data_mgmt.cu:792-794)
+    return 0;
+}
+
+int init_atomdata_impl(nbnxn_hip *nb, int natoms, int natoms_local, int ntype, const int *type)
+{
+    if (natoms < 0 || natoms_local < 0 || natoms_local > natoms) { return nbx_fail("bad atom counts %d/%d", natoms_local, natoms); }
+    if (natoms % (NBX_CLUSTER_SIZE * NBX_NCL_PER_SUPERCL) != 0) { return nbx_fail("natoms %d is not a multiple of 64 (padded super-clusters)", natoms); }
+    if (nb->ntype != 0 && ntype != nb->ntype) { return nbx_fail("atomdata has %d types, LJ table has %d", ntype, nb->ntype); }
+    for (int i = 0; i < natoms; i++)
+    {
+        if (type[i] < 0 || type[i] >= ntype) { return nbx_fail("atom %d has type %d outside [0,%d)", i, type[i], ntype); }
+    }
+    bool re = false;
+    if (dev_reserve(nb->xq, natoms) || dev_reserve(nb->type, natoms) || dev_reserve(nb->f, (size_t)natoms * 3, &re)) { return 1; }
+    nb->natoms = natoms; nb->natoms_local = natoms_local;
+    hipStream_t st = nb->stream[0];
+    if (re && natoms > 0)
+    {
+        // a new force array starts from zero (nbnxn_cuda_data_mgmt.cu:893-898)
+        HIP_TRY(hipMemsetAsync(nb->f.p, 0, nb->f.alloc * sizeof(float), st));
+    }
+    if (natoms > 0)
+    {
+        HIP_TRY(hipMemcpyAsync(nb->type.p, type, (size_t)natoms * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    // lists refer to the old atom arrays
+    nb->plist[0].nsci = 0; nb->plist[1].nsci = 0;
+    return 0;
+}
+
+int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
+{
+    if (check_loc(iloc)) { return 1; }
+    if (!nb->have_const) { return nbx_fail("launch before init_const"); }
+    PList &pl = nb->plist[iloc];
+    // don't launch the kernel if there is no work to do (nbnxn_cuda.cu:305-309)
+    if (pl.nsci == 0) { return 0; }
+    if (!nb->shift_vec_uploaded) { return nbx_fail("launch before upload_shiftvec"); }
+    hipStream_t st = nb->stream[iloc];
+    const bool  ener = (flags & NBX_FORCE_VIRIAL) != 0;   // energies and shift forces go together (:298-299)
+    int         begin, len;
+    loc_range(nb, iloc, &begin, &len);
+
+    if (nb->two_streams)
+    {
+        if (iloc == NBX_LOCAL) { HIP_TRY(hipEventRecord(nb->misc_ops_done, st)); }
+        else { HIP_TRY(hipStreamWaitEvent(st, nb->misc_ops_done, 0)); }
+    }
+    if (h_xq)
+    {
+        if (nb->do_time) { HIP_TRY(hipEventRecord(nb->h2d_start[iloc], st)); }
+        if (len > 0)
+        {
+            HIP_TRY(hipMemcpyAsync(nb->xq.p + begin, h_xq + (size_t)begin * 4, (size_t)len * sizeof(float4), hipMemcpyHostToDevice, st));
+        }
+        if (nb->do_time) { HIP_TRY(hipEventRecord(nb->h2d_stop[iloc], st)); nb->h2d_timed[iloc] = true; }
+    }
+
+    nbx_kernel_args_t a;
+    a.xq = nb->xq.p; a.f = nb->f.p; a.type = nb->type.p; a.shift_vec = nb->shift_vec; a.ntype = nb->ntype;
+    a.nbfp = nb->nbfp.p;
+    a.epsfac = nb->epsfac; a.inv_epsfac = 1.0f / nb->epsfac;
+    a.rc2 = nb->rcoulomb * nb->rcoulomb; a.rlist2 = pl.rlist * pl.rlist;
+    a.two_k_rf = 2 * nb->k_rf; a.c_rf = nb->c_rf;
+    a.beta = nb->beta; a.beta2 = nb->beta * nb->beta; a.beta3 = nb->beta * nb->beta * nb->beta;
+    a.sh_ewald = nb->sh_ewald; a.disp_cpot = nb->disp_cpot; a.rep_cpot = nb->rep_cpot;
+    a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.partial = pl.partial.p;
+
+    if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, st));
+    if (ener)
+    {
+        HIP_TRY(nbx_launch_reduce_outputs(pl.partial.p, pl.nsci, nb->fshift, nb->e_lj, nb->e_el, st));
+    }
+    if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
+    nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
+    return 0;
+}
+
+int cpyback_impl(nbnxn_hip *nb, float *h_f, int flags, int aloc)
+{
+    if (check_loc(aloc)) { return 1; }
+    const int iloc = aloc;
+    if (nb->plist[iloc].nsci == 0) { return 0; }
+    hipStream_t st = nb->stream[iloc];
+    const bool  ener = (flags & NBX_FORCE_VIRIAL) != 0;
+    int         begin, len;
+    loc_range(nb, aloc, &begin, &len);
+    if (nb->do_time) { HIP_TRY(hipEventRecord(nb->d2h_start[iloc], st)); }
+    // with two streams the local copy-back waits for the non-local kernel, which also
+    // writes local forces (nbnxn_cuda.cu:483-503)
+    if (iloc == NBX_LOCAL && nb->two_streams) { HIP_TRY(hipStreamWaitEvent(st, nb->nonlocal_done, 0)); }
+    if (len > 0 && h_f)
+    {
+        HIP_TRY(hipMemcpyAsync(h_f + (size_t)begin * 3, nb->f.p + (size_t)begin * 3, (size_t)len * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    if (iloc == NBX_NONLOCAL) { HIP_TRY(hipEventRecord(nb->nonlocal_done, st)); }
+    if (iloc == NBX_LOCAL && ener)
+    {
+        HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->e_lj, sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(nb->h_stage + 1, nb->e_el, sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(nb->h_stage + 2, nb->fshift, NBX_SHIFTS * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    if (nb->do_time) { HIP_TRY(hipEventRecord(nb->d2h_stop[iloc], st)); nb->d2h_timed[iloc] = true; }
+    return 0;
+}
+
+int wait_impl(nbnxn_hip *nb, int flags, int aloc, float *e_lj, float *e_el, float *fshift)
+{
+    if (check_loc(aloc)) { return 1; }
+    const int iloc = aloc;
+    PList    &pl   = nb->plist[iloc];
+    if (pl.nsci == 0) { return 0; }
+    const bool ener = (flags & NBX_FORCE_VIRIAL) != 0;
+    HIP_TRY(hipStreamSynchronize(nb->stream[iloc]));
+    if (nb->do_time)
+    {
+        nbx_wallclock_gpu_t &t = nb->timings;
+        const int pi = nb->last_prune[iloc] ? 1 : 0, ei = nb->last_ener[iloc] ? 1 : 0;
+        if (iloc == NBX_LOCAL) { t.nb_c++; t.ktime[pi][ei].c += 1; }
+        if (nb->k_timed[iloc]) { t.ktime[pi][ei].t += elapsed(nb->k_start[iloc], nb->k_stop[iloc]); }
+        if (nb->h2d_timed[iloc]) { t.nb_h2d_t += elapsed(nb->h2d_start[iloc], nb->h2d_stop[iloc]); nb->h2d_timed[iloc] = false; }
+        if (nb->d2h_timed[iloc]) { t.nb_d2h_t += elapsed(nb->d2h_start[iloc], nb->d2h_stop[iloc]); nb->d2h_timed[iloc] = false; }
+    }
+    // add up energies and shift forces, once, at the local wait (nbnxn_cuda.cu:662-680)
+    if (iloc == NBX_LOCAL && ener)
+    {
+        if (e_lj) { *e_lj += nb->h_stage[0]; }
+        if (e_el) { *e_el += nb->h_stage[1]; }
+        if (fshift)
+        {
+            for (int i = 0; i < NBX_SHIFTS * 3; i++) { fshift[i] += nb->h_stage[2 + i]; }
+        }
+    }
+    pl.do_prune = false;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+void nbnxn_hip_set_abort_on_error(int abort_on_error) { g_abort_on_error = abort_on_error; }
+const char *nbnxn_hip_last_error(void) { return g_last_error.c_str(); }
+
+int nbnxn_hip_detect_gpus(int *ngpu, char *err_str, int err_len)
+{
+    int        n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (ngpu) { *ngpu = (e == hipSuccess) ? n : 0; }
+    if (e != hipSuccess)
+    {
+        if (err_str && err_len > 0) { snprintf(err_str, err_len, "%s", hipGetErrorString(e)); }
+        return 1;
+    }
+    return 0;
+}
+
+int nbnxn_hip_init_gpu(int device_id, char *result_str, int result_len)
+{
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) { e = hipFree(nullptr); }   // force context creation, as init_gpu does
+    if (result_str && result_len > 0) { snprintf(result_str, result_len, "%s", e == hipSuccess ? "" : hipGetErrorString(e)); }
+    return e == hipSuccess ? 0 : 1;
+}
+
+int nbnxn_hip_free_gpu(char *result_str, int result_len)
+{
+    hipError_t e = hipDeviceReset();
+    if (result_str && result_len > 0) { snprintf(result_str, result_len, "%s", e == hipSuccess ? "" : hipGetErrorString(e)); }
+    return e == hipSuccess ? 0 : 1;
+}
+
+int nbnxn_hip_get_current_gpu_device_id(void)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { return -1; }
+    return d;
+}
+
+int nbnxn_hip_get_gpu_device_info_string(char *s, int len, int device_id)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device_id) != hipSuccess) { return nbx_fail("no device %d", device_id); }
+    snprintf(s, len, "#%d: %s (%s), %d CUs, %.0f GiB, clock %d MHz", device_id, p.name, p.gcnArchName,
+             p.multiProcessorCount, p.totalGlobalMem / 1073741824.0, p.clockRate / 1000);
+    return 0;
+}
+
+void nbnxn_hip_pmalloc(void **h_ptr, size_t nbytes)
+{
+    *h_ptr = nullptr;
+    if (nbytes == 0) { return; }
+    if (hipHostMalloc(h_ptr, nbytes, hipHostMallocDefault) != hipSuccess)
+    {
+        *h_ptr = nullptr;
+        nbx_fail("hipHostMalloc of %zu bytes failed", nbytes);
+    }
+}
+
+void nbnxn_hip_pfree(void *h_ptr)
+{
+    if (h_ptr && hipHostFree(h_ptr) != hipSuccess) { nbx_fail("hipHostFree failed"); }
+}
+
+int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocalAndNonlocal)
+{
+    if (!p_nb) { return nbx_fail("null output pointer"); }
+    *p_nb = nullptr;
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        return nbx_fail("device %d is %s; this library carries gfx950 (MI355X) code objects only", device_id, prop.gcnArchName);
+    }
+    nbnxn_hip *nb = new nbnxn_hip();
+    nb->device      = device_id;
+    nb->two_streams = bLocalAndNonlocal != 0;
+    HIP_TRY(hipStreamCreateWithFlags(&nb->stream[0], hipStreamNonBlocking));
+    if (nb->two_streams)
+    {
+        // the non-local work sits on the critical path of the halo exchange: high priority
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&nb->stream[1], hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&nb->misc_ops_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
+    }
+    else
+    {
+        nb->stream[1] = nb->stream[0];
+    }
+    nb->do_time = (getenv("GMX_DISABLE_HIP_TIMING") == nullptr);
+    for (int l = 0; l < 2; l++)
+    {
+        HIP_TRY(hipEventCreate(&nb->k_start[l]));   HIP_TRY(hipEventCreate(&nb->k_stop[l]));
+        HIP_TRY(hipEventCreate(&nb->h2d_start[l])); HIP_TRY(hipEventCreate(&nb->h2d_stop[l]));
+        HIP_TRY(hipEventCreate(&nb->d2h_start[l])); HIP_TRY(hipEventCreate(&nb->d2h_stop[l]));
+    }
+    HIP_TRY(hipMalloc((void **)&nb->shift_vec, NBX_SHIFTS * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&nb->fshift, NBX_SHIFTS * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&nb->e_lj, sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&nb->e_el, sizeof(float)));
+    HIP_TRY(hipHostMalloc((void **)&nb->h_stage, (2 + NBX_SHIFTS * 3) * sizeof(float), hipHostMallocDefault));
+    memset(&nb->timings, 0, sizeof(nb->timings));
+    if (clear_e_fshift(nb)) { return 1; }
+    HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    if (fplog)
+    {
+        fprintf(fplog, "Initialized HIP nonbonded module on device %d: %s (%s), %d CUs\n", device_id, prop.name,
+                prop.gcnArchName, prop.multiProcessorCount);
+    }
+    *p_nb = nb;
+    return 0;
+}
+
+int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type, float rcoulomb, float rvdw, float rlist,
+                              float epsfac, float k_rf, float c_rf, float ewaldcoeff_q, float sh_ewald,
+                              float disp_cpot, float rep_cpot, int ntype, const float *nbfp)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    if (set_params(nb, el_type, rcoulomb, rvdw, rlist, epsfac, k_rf, c_rf, ewaldcoeff_q, sh_ewald, disp_cpot, rep_cpot)) { return 1; }
+    if (upload_nbfp(nb, ntype, nbfp)) { return 1; }
+    if (clear_e_fshift(nb)) { return 1; }
+    HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    return 0;
+}
+
+int nbnxn_hip_init_const(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic, const nbx_verlet_group_t *nbv_group)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!ic || !nbv_group || !nbv_group[0].nbat) { return nbx_fail("init_const: missing interaction constants or atom data"); }
+    const nbx_atomdata_t *nbat = nbv_group[0].nbat;
+    int                   el;
+    // flavour choice of nbnxn_cuda_data_mgmt.cu:303-357, reduced to what is built here
+    if (ic->vdwtype != NBX_VDW_CUT || !(ic->vdw_modifier == NBX_MOD_NONE || ic->vdw_modifier == NBX_MOD_POTSHIFT))
+    {
+        return nbx_fail("VdW type %d / modifier %d is not built yet (plain cut-off with or without potential shift only)", ic->vdwtype, ic->vdw_modifier);
+    }
+    if (ic->eeltype == NBX_EEL_CUT || ic->eeltype == NBX_EEL_RF || ic->eeltype == NBX_EEL_GRF) { el = NBX_EL_RF; }
+    else if (ic->eeltype == NBX_EEL_PME || ic->eeltype == NBX_EEL_EWALD) { el = NBX_EL_EWALD_ANA; }
+    else { return nbx_fail("The requested electrostatics type %d is not implemented in the HIP GPU accelerated kernels!", ic->eeltype); }
+    // eelCUT runs the RF kernel with k_rf = 0, c_rf = 1/rc as the reference sets them (forcerec.c:2072-2079)
+    return nbnxn_hip_init_const_flat(nb, el, ic->rcoulomb, ic->rvdw, ic->rlist, ic->epsfac, ic->k_rf, ic->c_rf,
+                                     ic->ewaldcoeff_q, ic->sh_ewald, ic->dispersion_shift.cpot, ic->repulsion_shift.cpot,
+                                     nbat->ntype, nbat->nbfp);
+}
+
+int nbnxn_hip_pme_loadbal_update_param(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->have_const) { return nbx_fail("pme_loadbal_update_param before init_const"); }
+    return set_params(nb, nb->el_type, ic->rcoulomb, ic->rvdw, ic->rlist, ic->epsfac, ic->k_rf, ic->c_rf,
+                      ic->ewaldcoeff_q, ic->sh_ewald, ic->dispersion_shift.cpot, ic->repulsion_shift.cpot);
+}
+
+int nbnxn_hip_init_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc, float rlist, int nsci, const nbx_sci_t *sci,
+                                 int ncj4, const nbx_cj4_t *cj4, int nexcl, const nbx_excl_t *excl, int nci_tot)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    return init_pairlist_impl(nb, iloc, rlist, nsci, sci, ncj4, cj4, nexcl, excl, nci_tot);
+}
+
+int nbnxn_hip_init_pairlist(nbnxn_hip_ptr_t nb, const nbx_pairlist_t *l, int iloc)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!l) { return nbx_fail("null pair list"); }
+    if (l->bSimple || l->na_ci != NBX_CLUSTER_SIZE || l->na_cj != NBX_CLUSTER_SIZE)
+    {
+        return nbx_fail("The pair list is not in the 8x8x8 GPU format (bSimple %d, cluster size %d)", l->bSimple, l->na_ci);
+    }
+    return nbnxn_hip_init_pairlist_flat(nb, iloc, l->rlist, l->nsci, l->sci, l->ncj4, l->cj4, l->nexcl, l->excl, l->nci_tot);
+}
+
+int nbnxn_hip_init_atomdata_flat(nbnxn_hip_ptr_t nb, int natoms, int natoms_local, int ntype, const int *type)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    return init_atomdata_impl(nb, natoms, natoms_local, ntype, type);
+}
+
+int nbnxn_hip_init_atomdata(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nbat) { return nbx_fail("null atom data"); }
+    if (nbat->xstride != 4 || nbat->fstride != 3) { return nbx_fail("atom data must be XYZQ/XYZ (xstride 4, fstride 3), got %d/%d", nbat->xstride, nbat->fstride); }
+    return nbnxn_hip_init_atomdata_flat(nb, nbat->natoms, nbat->natoms_local, nbat->ntype, nbat->type);
+}
+
+int nbnxn_hip_upload_shiftvec_flat(nbnxn_hip_ptr_t nb, const float *shift_vec)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(hipMemcpyAsync(nb->shift_vec, shift_vec, NBX_SHIFTS * 3 * sizeof(float), hipMemcpyHostToDevice, nb->stream[0]));
+    HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    nb->shift_vec_uploaded = true;
+    return 0;
+}
+
+int nbnxn_hip_upload_shiftvec(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat)
+{
+    if (check_handle(nb)) { return 1; }
+    // only if the box changes or nothing was uploaded yet (nbnxn_cuda_data_mgmt.cu:803-814)
+    if (nbat->bDynamicBox || !nb->shift_vec_uploaded)
+    {
+        return nbnxn_hip_upload_shiftvec_flat(nb, &nbat->shift_vec[0][0]);
+    }
+    return 0;
+}
+
+int nbnxn_hip_clear_outputs(nbnxn_hip_ptr_t nb, int flags)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    if (nb->natoms > 0) { HIP_TRY(hipMemsetAsync(nb->f.p, 0, (size_t)nb->natoms * 3 * sizeof(float), nb->stream[0])); }
+    if (flags & NBX_FORCE_VIRIAL)
+    {
+        if (clear_e_fshift(nb)) { return 1; }
+    }
+    return 0;
+}
+
+int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
+{
+    if (!nb) { return 0; }
+    (void)hipSetDevice(nb->device);
+    (void)hipDeviceSynchronize();
+    dev_free(nb->xq); dev_free(nb->f); dev_free(nb->type); dev_free(nb->nbfp);
+    for (int l = 0; l < 2; l++)
+    {
+        dev_free(nb->plist[l].sci); dev_free(nb->plist[l].cj4); dev_free(nb->plist[l].excl); dev_free(nb->plist[l].partial);
+        (void)hipEventDestroy(nb->k_start[l]);   (void)hipEventDestroy(nb->k_stop[l]);
+        (void)hipEventDestroy(nb->h2d_start[l]); (void)hipEventDestroy(nb->h2d_stop[l]);
+        (void)hipEventDestroy(nb->d2h_start[l]); (void)hipEventDestroy(nb->d2h_stop[l]);
+    }
+    (void)hipFree(nb->shift_vec); (void)hipFree(nb->fshift); (void)hipFree(nb->e_lj); (void)hipFree(nb->e_el);
+    (void)hipHostFree(nb->h_stage);
+    if (nb->two_streams)
+    {
+        (void)hipEventDestroy(nb->misc_ops_done); (void)hipEventDestroy(nb->nonlocal_done);
+        (void)hipStreamDestroy(nb->stream[1]);
+    }
+    (void)hipStreamDestroy(nb->stream[0]);
+    delete nb;
+    return 0;
+}
+
+nbx_wallclock_gpu_t *nbnxn_hip_get_timings(nbnxn_hip_ptr_t nb)
+{
+    return (nb && nb->do_time) ? &nb->timings : nullptr;
+}
+
+int nbnxn_hip_reset_timings(nbnxn_hip_ptr_t nb)
+{
+    if (check_handle(nb)) { return 1; }
+    memset(&nb->timings, 0, sizeof(nb->timings));
+    return 0;
+}
+
+int nbnxn_hip_min_ci_balanced(nbnxn_hip_ptr_t nb)
+{
+    // The reference asks for 40 entries per multiprocessor (nbnxn_cuda_data_mgmt.cu:76).
+    // One entry is one wave64 here and a CU runs up to 32 of them (8 per SIMD), so the
+    // same factor keeps every SIMD supplied with several waves over the kernel's tail.
+    int        ncu = 256;
+    hipDeviceProp_t p;
+    if (nb && hipGetDeviceProperties(&p, nb->device) == hipSuccess) { ncu = p.multiProcessorCount; }
+    return 40 * ncu;
+}
+
+int nbnxn_hip_is_kernel_ewald_analytical(const nbnxn_hip_ptr_t nb) { return nb && nb->el_type == NBX_EL_EWALD_ANA; }
+
+int nbnxn_hip_launch_kernel_flat(nbnxn_hip_ptr_t nb, const float *xq, int flags, int iloc)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!xq) { return nbx_fail("null coordinates"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    return launch_impl(nb, xq, flags, iloc);
+}
+
+int nbnxn_hip_launch_kernel(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags, int iloc)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nbat || nbat->natoms != nb->natoms) { return nbx_fail("atom data does not match init_atomdata"); }
+    return nbnxn_hip_launch_kernel_flat(nb, nbat->x, flags, iloc);
+}
+
+int nbnxn_hip_launch_kernel_resident(nbnxn_hip_ptr_t nb, int flags, int iloc)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    return launch_impl(nb, nullptr, flags, iloc);
+}
+
+int nbnxn_hip_launch_cpyback_flat(nbnxn_hip_ptr_t nb, float *f, int flags, int aloc)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    return cpyback_impl(nb, f, flags, aloc);
+}
+
+int nbnxn_hip_launch_cpyback(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags, int aloc)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nbat || !nbat->out || !nbat->out[0].f) { return nbx_fail("atom data has no force output"); }
+    return nbnxn_hip_launch_cpyback_flat(nb, nbat->out[0].f, flags, aloc);
+}
+
+int nbnxn_hip_wait_gpu_flat(nbnxn_hip_ptr_t nb, int flags, int aloc, float *e_lj, float *e_el, float *fshift)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    return wait_impl(nb, flags, aloc, e_lj, e_el, fshift);
+}
+
+int nbnxn_hip_wait_gpu(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags, int aloc,
+                       float *e_lj, float *e_el, float (*fshift)[3])
+{
+    (void)nbat;
+    return nbnxn_hip_wait_gpu_flat(nb, flags, aloc, e_lj, e_el, fshift ? &fshift[0][0] : nullptr);
+}
+
+int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, void **d_type)
+{
+    if (check_handle(nb)) { return 1; }
+    if (d_xq) { *d_xq = nb->xq.p; }
+    if (d_f) { *d_f = nb->f.p; }
+    if (d_type) { *d_type = nb->type.p; }
+    return 0;
+}
+
+void *nbnxn_hip_get_stream(nbnxn_hip_ptr_t nb, int iloc)
+{
+    if (!nb || iloc < 0 || iloc > 1) { return nullptr; }
+    return (void *)nb->stream[iloc];
+}
+
+int nbnxn_hip_read_outputs(nbnxn_hip_ptr_t nb, float *e_lj, float *e_el, float *fshift)
+{
+    if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = nb->stream[0];
+    if (nb->two_streams) { HIP_TRY(hipStreamSynchronize(nb->stream[1])); }
+    HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->e_lj, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nb->h_stage + 1, nb->e_el, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nb->h_stage + 2, nb->fshift, NBX_SHIFTS * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (e_lj) { *e_lj = nb->h_stage[0]; }
+    if (e_el) { *e_el = nb->h_stage[1]; }
+    if (fshift) { memcpy(fshift, nb->h_stage + 2, NBX_SHIFTS * 3 * sizeof(float)); }
+    return 0;
+}
+
+int nbnxn_hip_download_cj4(nbnxn_hip_ptr_t nb, int iloc, int ncj4, nbx_cj4_t *cj4)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    if (ncj4 != nb->plist[iloc].ncj4) { return nbx_fail("list on the device has %d cj4 entries, caller asked for %d", nb->plist[iloc].ncj4, ncj4); }
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(hipStreamSynchronize(nb->stream[iloc]));
+    if (ncj4 > 0) { HIP_TRY(hipMemcpy(cj4, nb->plist[iloc].cj4.p, (size_t)ncj4 * sizeof(nbx_cj4_t), hipMemcpyDeviceToHost)); }
+    return 0;
+}
+
+int nbnxn_hip_verify_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc, int nsci, const nbx_sci_t *sci,
+                                   int ncj4, const nbx_cj4_t *cj4, int nexcl, const nbx_excl_t *excl)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return -1; }
+    PList &pl = nb->plist[iloc];
+    if (nsci != pl.nsci || ncj4 != pl.ncj4 || nexcl != pl.nexcl)
+    {
+        nbx_fail("list sizes differ: device %d/%d/%d, host %d/%d/%d", pl.nsci, pl.ncj4, pl.nexcl, nsci, ncj4, nexcl);
+        return -1;
+    }
+    if (hipSetDevice(nb->device) != hipSuccess || hipStreamSynchronize(nb->stream[iloc]) != hipSuccess) { return -1; }
+    std::vector<nbx_sci_t>  dsci(nsci);
+    std::vector<nbx_cj4_t>  dcj4(ncj4);
+    std::vector<nbx_excl_t> dexcl(nexcl);
+    if ((nsci && hipMemcpy(dsci.data(), pl.sci.p, (size_t)nsci * sizeof(nbx_sci_t), hipMemcpyDeviceToHost) != hipSuccess) ||
+        (ncj4 && hipMemcpy(dcj4.data(), pl.cj4.p, (size_t)ncj4 * sizeof(nbx_cj4_t), hipMemcpyDeviceToHost) != hipSuccess) ||
+        (nexcl && hipMemcpy(dexcl.data(), pl.excl.p, (size_t)nexcl * sizeof(nbx_excl_t), hipMemcpyDeviceToHost) != hipSuccess))
+    {
+        nbx_fail("read-back of the pair list failed");
+        return -1;
+    }
+    int ndiff = 0;
+    for (int s = 0; s < nsci; s++) { ndiff += memcmp(&dsci[s], &sci[s], sizeof(nbx_sci_t)) != 0; }
+    for (int c = 0; c < ncj4; c++)
+    {
+        for (int w = 0; w < 2; w++)
+        {
+            ndiff += dcj4[c].imei[w].imask != cj4[c].imei[w].imask;
+            ndiff += dcj4[c].imei[w].excl_ind != cj4[c].imei[w].excl_ind;
+        }
+        const unsigned m = cj4[c].imei[0].imask | cj4[c].imei[1].imask;
+        for (int jm = 0; jm < 4; jm++)
+        {
+            // slots without interaction bits are padding with undefined cj (SURVEY 8a trap 1)
+            if ((m >> (8 * jm)) & 0xffu) { ndiff += dcj4[c].cj[jm] != cj4[c].cj[jm]; }
+        }
+    }
+    for (int x = 0; x < nexcl; x++)
+    {
+        for (int t = 0; t < 32; t++) { ndiff += dexcl[x].pair[t] != excl[x].pair[t]; }
+    }
+    return ndiff;
+}
+
+float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc)
+{
+    if (!nb || iloc < 0 || iloc > 1 || !nb->do_time || !nb->k_timed[iloc]) { return -1.0f; }
+    if (hipEventSynchronize(nb->k_stop[iloc]) != hipSuccess) { return -1.0f; }
+    return elapsed(nb->k_start[iloc], nb->k_stop[iloc]);
+}
+
+int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    nb->plist[iloc].do_prune = do_prune != 0;
+    return 0;
+}
+
+int nbnxn_hip_set_kernel_variant(nbnxn_hip_ptr_t nb, int variant)
+{
+    if (check_handle(nb)) { return 1; }
+    nb->variant = variant;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,350 @@
+// gfx950 (MI355X) cluster-pair nonbonded kernels.
+//
+// One wave64 per i-super-cluster entry (nbnxn_sci_t); the 8x8 atom pairs of an
+// (i-cluster, j-cluster) pair map onto the 64 lanes: lane = 8*jatom + iatom, so lanes
+// 0-31 / 32-63 read the exclusion words of list half 0 / 1 (types/nbnxn_pairlist.h:109-123).
+// What is computed per pair follows the reference kernels (nbnxn_cuda_kernel.cuh:270-506,
+// nbnxn_kernel_ref_inner.h:117-372); how it is mapped to the hardware is gfx950-specific:
+//   * i-atom xyz, epsfac*q and type rows are staged once per entry in LDS;
+//   * j-atom xq/type are read straight from HBM/L2, 8 distinct 16-B rows per wave load;
+//   * j-forces: 3-step DPP reduction over the 8 i-lanes, then ONE 24-lane fp32 atomic
+//     instruction covering the cluster's 96 contiguous bytes of f;
+//   * i-forces: 24 register accumulators per lane, reduce-scattered over the 8 j-lanes at
+//     the end (21 cross-lane moves), transposed through LDS and written with three
+//     256-byte contiguous atomic instructions;
+//   * energies / shift forces: per-entry partial sums stored to HBM and folded in double
+//     precision by nbnxn_reduce_outputs (no same-address fp32 atomic chain).
+#include <hip/hip_runtime.h>
+
+#include "nbnxn_kernel.h"
+
+namespace {
+
+// Ewald real-space correction g(w) = -(erf(z)/z - 2/sqrt(pi) exp(-z^2))/z^2, w = z^2, as
+// P6(w)/Q4(w); coefficients derived by tools/fit_pmecorr.py (max abs error 1.6e-7 in
+// float on 0 <= w <= 16).
+#define NBX_PMEF_P0 -7.522527264e-01f
+#define NBX_PMEF_P1 8.071402458e-02f
+#define NBX_PMEF_P2 -2.010053827e-02f
+#define NBX_PMEF_P3 1.231729042e-03f
+#define NBX_PMEF_P4 -6.630095574e-05f
+#define NBX_PMEF_P5 1.910048934e-06f
+#define NBX_PMEF_P6 -2.368872454e-08f
+#define NBX_PMEF_Q1 4.927010142e-01f
+#define NBX_PMEF_Q2 1.080706215e-01f
+#define NBX_PMEF_Q3 1.314706087e-02f
+#define NBX_PMEF_Q4 8.677762527e-04f
+
+__device__ __forceinline__ float pme_corr_f(float w)
+{
+    float p = NBX_PMEF_P6;
+    p = fmaf(p, w, NBX_PMEF_P5);
+    p = fmaf(p, w, NBX_PMEF_P4);
+    p = fmaf(p, w, NBX_PMEF_P3);
+    p = fmaf(p, w, NBX_PMEF_P2);
+    p = fmaf(p, w, NBX_PMEF_P1);
+    p = fmaf(p, w, NBX_PMEF_P0);
+    float q = NBX_PMEF_Q4;
+    q = fmaf(q, w, NBX_PMEF_Q3);
+    q = fmaf(q, w, NBX_PMEF_Q2);
+    q = fmaf(q, w, NBX_PMEF_Q1);
+    q = fmaf(q, w, 1.0f);
+    return p * __builtin_amdgcn_rcpf(q);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, m);
+}
+
+// sum over the 8 lanes that share a j-atom (lane bits 0..2)
+__device__ __forceinline__ float reduce8(float v)
+{
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v = reduce8(v);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+constexpr int MAX_LDS_TYPES = NBX_KERNEL_MAX_LDS_TYPES;
+
+template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
+__global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
+{
+    const int lane  = threadIdx.x;
+    const int tidxi = lane & 7;
+    const int tidxj = lane >> 3;
+
+    __shared__ float4 s_xqi[64];
+    __shared__ int    s_ti[64];
+    __shared__ float  s_red[192];
+    __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
+
+    const nbx_sci_t e     = a.sci[blockIdx.x];
+    const int       sci   = e.sci;
+    const int       ntype = a.ntype;
+    const bool      central = (e.shift == NBX_CENTRAL);
+
+    {
+        const int ai = sci * 64 + lane;
+        float4    xi = a.xq[ai];
+        xi.x += a.shift_vec[3 * e.shift + 0];
+        xi.y += a.shift_vec[3 * e.shift + 1];
+        xi.z += a.shift_vec[3 * e.shift + 2];
+        xi.w *= a.epsfac;
+        s_xqi[lane] = xi;
+        s_ti[lane]  = a.type[ai] * ntype;
+        if (NBFP_LDS)
+        {
+            for (int k = lane; k < ntype * ntype; k += 64) { s_nbfp[k] = a.nbfp[k]; }
+        }
+    }
+    __syncthreads();
+
+    float fix[8], fiy[8], fiz[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { fix[i] = 0; fiy[i] = 0; fiz[i] = 0; }
+
+    float E_lj = 0, E_el = 0;
+
+    if (ENER)
+    {
+        // self term once per diagonal entry (nbnxn_cuda_kernel.cuh:222-256); q is already
+        // multiplied by epsfac, so divide one factor out
+        if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
+        {
+            const float q  = s_xqi[lane].w;
+            const float q2 = q * q * a.inv_epsfac;
+            E_el = (EL == NBX_EL_RF) ? -0.5f * a.c_rf * q2 : -a.beta * 0.564189583547756f * q2;
+        }
+    }
+
+    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
+    {
+        unsigned       imask = a.cj4[j4].imei[0].imask | a.cj4[j4].imei[1].imask;
+        if (!PRUNE && imask == 0) { continue; }
+        const unsigned wexcl = a.excl[a.cj4[j4].imei[lane >> 5].excl_ind].pair[lane & 31];
+
+        for (int jm = 0; jm < 4; jm++)
+        {
+            if (!(imask & (0xffu << (jm * 8)))) { continue; }
+            const int    cj    = a.cj4[j4].cj[jm];
+            const int    aj    = cj * 8 + tidxj;
+            const float4 xj    = a.xq[aj];
+            const int    typej = a.type[aj];
+            float        fjx = 0, fjy = 0, fjz = 0;
+            const unsigned ebits = wexcl >> (jm * 8);
+
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                const unsigned bit = 1u << (jm * 8 + i);
+                if (imask & bit)
+                {
+                    const float4 xi = s_xqi[i * 8 + tidxi];
+                    const float  dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                    float        r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    if (PRUNE)
+                    {
+                        // a cluster pair with no atom pair inside rlist leaves the list
+                        // (nbnxn_cuda_kernel.cuh:332-340); wave-wide, so both halves agree
+                        if (!__any(r2 < a.rlist2)) { imask &= ~bit; }
+                    }
+                    const float int_bit = (ebits >> i) & 1u ? 1.0f : 0.0f;
+                    // cut-off, and on the diagonal cluster pair only j > i (:346-347)
+                    const bool  diag = central && (cj == sci * 8 + i);
+                    if (r2 < a.rc2 && (!diag || tidxj > tidxi))
+                    {
+                        float c6, c12;
+                        if (NBFP_LDS)
+                        {
+                            const float2 c = s_nbfp[s_ti[i * 8 + tidxi] + typej];
+                            c6 = c.x; c12 = c.y;
+                        }
+                        else
+                        {
+                            const float2 c = a.nbfp[s_ti[i * 8 + tidxi] + typej];
+                            c6 = c.x; c12 = c.y;
+                        }
+                        r2 = fmaf(1.0f - int_bit, NBX_AVOID_SING_R2_INC, r2);
+                        const float inv_r  = __builtin_amdgcn_rsqf(r2);
+                        const float inv_r2 = inv_r * inv_r;
+                        const float inv_r6 = inv_r2 * inv_r2 * inv_r2 * int_bit;
+                        float       F      = inv_r6 * fmaf(c12, inv_r6, -c6) * inv_r2;
+                        const float qq     = xi.w * xj.w;
+                        if (ENER)
+                        {
+                            E_lj += int_bit * (c12 * fmaf(inv_r6, inv_r6, a.rep_cpot) * (1.0f / 12.0f)
+                                               - c6 * (inv_r6 + a.disp_cpot) * (1.0f / 6.0f));
+                        }
+                        if (EL == NBX_EL_RF)
+                        {
+                            F = fmaf(qq, fmaf(int_bit, inv_r2 * inv_r, -a.two_k_rf), F);
+                            if (ENER) { E_el += qq * (fmaf(int_bit, inv_r, 0.5f * a.two_k_rf * r2) - a.c_rf); }
+                        }
+                        else
+                        {
+                            F = fmaf(qq, fmaf(int_bit, inv_r2 * inv_r, pme_corr_f(a.beta2 * r2) * a.beta3), F);
+                            if (ENER)
+                            {
+                                E_el += qq * (inv_r * (int_bit - erff(r2 * inv_r * a.beta)) - int_bit * a.sh_ewald);
+                            }
+                        }
+                        fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
+                        fix[i] = fmaf(dx, F, fix[i]); fiy[i] = fmaf(dy, F, fiy[i]); fiz[i] = fmaf(dz, F, fiz[i]);
+                    }
+                }
+            }
+
+            // j-force: sum over the 8 i-lanes, then lanes i = 0,1,2 add x,y,z: 24 lanes,
+            // 96 contiguous bytes, one atomic instruction
+            fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
+            const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
+            if (tidxi < 3) { atomicAdd(&a.f[aj * 3 + tidxi], fj); }
+        }
+
+        if (PRUNE)
+        {
+            if (lane == 0)
+            {
+                a.cj4[j4].imei[0].imask = imask;
+                a.cj4[j4].imei[1].imask = imask;
+            }
+        }
+    }
+
+    // i-forces: reduce-scatter over the 8 j-lanes (lane bits 5,4,3); lane (j,i) ends up
+    // with the total of i-cluster j, atom i, i.e. of atom sci*64 + lane
+    float rx, ry, rz;
+    {
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        float      gx[4], gy[4], gz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            gx[k] = (h5 ? fix[k + 4] : fix[k]) + __shfl_xor(h5 ? fix[k] : fix[k + 4], 32);
+            gy[k] = (h5 ? fiy[k + 4] : fiy[k]) + __shfl_xor(h5 ? fiy[k] : fiy[k + 4], 32);
+            gz[k] = (h5 ? fiz[k + 4] : fiz[k]) + __shfl_xor(h5 ? fiz[k] : fiz[k + 4], 32);
+        }
+        float hx[2], hy[2], hz[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            hx[k] = (h4 ? gx[k + 2] : gx[k]) + __shfl_xor(h4 ? gx[k] : gx[k + 2], 16);
+            hy[k] = (h4 ? gy[k + 2] : gy[k]) + __shfl_xor(h4 ? gy[k] : gy[k + 2], 16);
+            hz[k] = (h4 ? gz[k + 2] : gz[k]) + __shfl_xor(h4 ? gz[k] : gz[k + 2], 16);
+        }
+        rx = (h3 ? hx[1] : hx[0]) + __shfl_xor(h3 ? hx[0] : hx[1], 8);
+        ry = (h3 ? hy[1] : hy[0]) + __shfl_xor(h3 ? hy[0] : hy[1], 8);
+        rz = (h3 ? hz[1] : hz[0]) + __shfl_xor(h3 ? hz[0] : hz[1], 8);
+    }
+    s_red[lane * 3 + 0] = rx;
+    s_red[lane * 3 + 1] = ry;
+    s_red[lane * 3 + 2] = rz;
+    __syncthreads();
+    {
+        float *fi = a.f + (size_t)sci * 192;
+        atomicAdd(&fi[lane], s_red[lane]);
+        atomicAdd(&fi[lane + 64], s_red[lane + 64]);
+        atomicAdd(&fi[lane + 128], s_red[lane + 128]);
+    }
+
+    if (ENER)
+    {
+        // per-entry partials: shift force (not for the central shift, whose virial
+        // contribution is zero: nbnxn_cuda_kernel.cuh:261-265) and the two energies
+        const float sx = central ? 0.0f : wave_sum(rx);
+        const float sy = central ? 0.0f : wave_sum(ry);
+        const float sz = central ? 0.0f : wave_sum(rz);
+        E_lj = wave_sum(E_lj);
+        E_el = wave_sum(E_el);
+        if (lane == 0)
+        {
+            float *p = a.partial + (size_t)blockIdx.x * NBX_PARTIAL_STRIDE;
+            p[0] = sx; p[1] = sy; p[2] = sz; p[3] = E_lj; p[4] = E_el;
+            reinterpret_cast<int *>(p)[5] = e.shift;
+        }
+    }
+}
+
+// Folds the per-entry partials into fshift[45][3], e_lj, e_el (ADDS to them, so that local
+// and non-local launches accumulate like the reference's atomics do).  One block.
+__global__ void __launch_bounds__(256) nbnxn_reduce_outputs(const float *partial, int nsci,
+                                                            float *fshift, float *e_lj, float *e_el)
+{
+    __shared__ double acc[NBX_SHIFTS * 3 + 2];
+    for (int k = threadIdx.x; k < NBX_SHIFTS * 3 + 2; k += blockDim.x) { acc[k] = 0; }
+    __syncthreads();
+    double elj = 0, eel = 0;
+    for (int s = threadIdx.x; s < nsci; s += blockDim.x)
+    {
+        const float *p  = partial + (size_t)s * NBX_PARTIAL_STRIDE;
+        const int    sh = reinterpret_cast<const int *>(p)[5];
+        if (sh != NBX_CENTRAL)
+        {
+            atomicAdd(&acc[3 * sh + 0], (double)p[0]);
+            atomicAdd(&acc[3 * sh + 1], (double)p[1]);
+            atomicAdd(&acc[3 * sh + 2], (double)p[2]);
+        }
+        elj += p[3];
+        eel += p[4];
+    }
+    atomicAdd(&acc[NBX_SHIFTS * 3], elj);
+    atomicAdd(&acc[NBX_SHIFTS * 3 + 1], eel);
+    __syncthreads();
+    for (int k = threadIdx.x; k < NBX_SHIFTS * 3; k += blockDim.x) { fshift[k] += (float)acc[k]; }
+    if (threadIdx.x == 0)
+    {
+        *e_lj += (float)acc[NBX_SHIFTS * 3];
+        *e_el += (float)acc[NBX_SHIFTS * 3 + 1];
+    }
+}
+
+template <int EL, bool ENER, bool PRUNE>
+void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
+{
+    if (a.ntype <= MAX_LDS_TYPES)
+    {
+        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, a);
+    }
+    else
+    {
+        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, a);
+    }
+}
+
+} // namespace
+
+hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
+                                hipStream_t stream)
+{
+    if (nsci <= 0) { return hipSuccess; }
+#define NBX_DISPATCH(EL)                                                                     \
+    if (ener) { if (prune) { launch_flavour<EL, true, true>(a, nsci, stream); }              \
+                else       { launch_flavour<EL, true, false>(a, nsci, stream); } }           \
+    else      { if (prune) { launch_flavour<EL, false, true>(a, nsci, stream); }             \
+                else       { launch_flavour<EL, false, false>(a, nsci, stream); } }
+    if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF) }
+    else { NBX_DISPATCH(NBX_EL_EWALD_ANA) }
+#undef NBX_DISPATCH
+    return hipGetLastError();
+}
+
+hipError_t nbx_launch_reduce_outputs(const float *partial, int nsci, float *fshift, float *e_lj, float *e_el,
+                                     hipStream_t stream)
+{
+    if (nsci <= 0) { return hipSuccess; }
+    hipLaunchKernelGGL(nbnxn_reduce_outputs, dim3(1), dim3(256), 0, stream, partial, nsci, fshift, e_lj, e_el);
+    return hipGetLastError();
+}

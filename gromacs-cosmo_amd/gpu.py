@@ -1,0 +1,221 @@
+"""Python mirror of the C ABI in include/nbnxn_hip.h (libnbnxn_hip.so), with the same call
+names and argument meaning as the reference's nbnxn_cuda_* module
+(legacyheaders/nbnxn_cuda_data_mgmt.h:59-139, mdlib/nbnxn_cuda/nbnxn_cuda.h:64-86).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is present,
+every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(abi.lib_dir(), "libnbnxn_hip.so")
+    if not os.path.exists(path):
+        raise HipError(f"{path} is missing: the HIP extension was not built (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(path)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.nbnxn_hip_last_error.restype = C.c_char_p
+    lib.nbnxn_hip_set_abort_on_error.argtypes = [ci]
+    lib.nbnxn_hip_detect_gpus.argtypes = [C.POINTER(ci), C.c_char_p, ci]
+    lib.nbnxn_hip_get_gpu_device_info_string.argtypes = [C.c_char_p, ci, ci]
+    lib.nbnxn_hip_pmalloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.nbnxn_hip_pfree.argtypes = [vp]
+    lib.nbnxn_hip_init.argtypes = [vp, C.POINTER(vp), ci, ci]
+    lib.nbnxn_hip_init_const.argtypes = [vp, C.POINTER(abi.InteractionConst), C.POINTER(abi.VerletGroup)]
+    lib.nbnxn_hip_init_const_flat.argtypes = [vp, ci] + [cf] * 10 + [ci, vp]
+    lib.nbnxn_hip_init_pairlist.argtypes = [vp, C.POINTER(abi.Pairlist), ci]
+    lib.nbnxn_hip_init_pairlist_flat.argtypes = [vp, ci, cf, ci, vp, ci, vp, ci, vp, ci]
+    lib.nbnxn_hip_init_atomdata.argtypes = [vp, C.POINTER(abi.Atomdata)]
+    lib.nbnxn_hip_init_atomdata_flat.argtypes = [vp, ci, ci, ci, vp]
+    lib.nbnxn_hip_pme_loadbal_update_param.argtypes = [vp, C.POINTER(abi.InteractionConst)]
+    lib.nbnxn_hip_upload_shiftvec.argtypes = [vp, C.POINTER(abi.Atomdata)]
+    lib.nbnxn_hip_upload_shiftvec_flat.argtypes = [vp, vp]
+    lib.nbnxn_hip_clear_outputs.argtypes = [vp, ci]
+    lib.nbnxn_hip_free.argtypes = [vp]
+    lib.nbnxn_hip_get_timings.argtypes = [vp]
+    lib.nbnxn_hip_get_timings.restype = C.POINTER(abi.WallclockGpu)
+    lib.nbnxn_hip_reset_timings.argtypes = [vp]
+    lib.nbnxn_hip_min_ci_balanced.argtypes = [vp]
+    lib.nbnxn_hip_is_kernel_ewald_analytical.argtypes = [vp]
+    lib.nbnxn_hip_launch_kernel.argtypes = [vp, C.POINTER(abi.Atomdata), ci, ci]
+    lib.nbnxn_hip_launch_kernel_flat.argtypes = [vp, vp, ci, ci]
+    lib.nbnxn_hip_launch_kernel_resident.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_launch_cpyback.argtypes = [vp, C.POINTER(abi.Atomdata), ci, ci]
+    lib.nbnxn_hip_launch_cpyback_flat.argtypes = [vp, vp, ci, ci]
+    lib.nbnxn_hip_wait_gpu.argtypes = [vp, C.POINTER(abi.Atomdata), ci, ci, vp, vp, vp]
+    lib.nbnxn_hip_wait_gpu_flat.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.nbnxn_hip_get_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.nbnxn_hip_get_stream.argtypes = [vp, ci]
+    lib.nbnxn_hip_get_stream.restype = vp
+    lib.nbnxn_hip_read_outputs.argtypes = [vp, vp, vp, vp]
+    lib.nbnxn_hip_verify_pairlist_flat.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp]
+    lib.nbnxn_hip_download_cj4.argtypes = [vp, ci, ci, vp]
+    lib.nbnxn_hip_last_kernel_ms.argtypes = [vp, ci]
+    lib.nbnxn_hip_last_kernel_ms.restype = cf
+    lib.nbnxn_hip_set_prune.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_set_kernel_variant.argtypes = [vp, ci]
+    # the host runtime raises instead of aborting the interpreter (gmx_fatal would abort)
+    lib.nbnxn_hip_set_abort_on_error(0)
+    _lib = lib
+    return lib
+
+
+def detect_gpus():
+    lib = load()
+    n = C.c_int(0)
+    buf = C.create_string_buffer(256)
+    rc = lib.nbnxn_hip_detect_gpus(C.byref(n), buf, 256)
+    if rc != 0:
+        raise HipError("no usable GPU: " + buf.value.decode())
+    return n.value
+
+
+class NbnxnHip:
+    """One nbnxn_hip handle (the reference's nbnxn_cuda_ptr_t)."""
+
+    def __init__(self, device_id=0, local_and_nonlocal=False):
+        self.lib = load()
+        self.h = C.c_void_p()
+        self._chk(self.lib.nbnxn_hip_init(None, C.byref(self.h), device_id, int(local_and_nonlocal)))
+        self.natoms = 0
+        self._keep = {}
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.lib.nbnxn_hip_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nbnxn_hip_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- data management (nbnxn_cuda_data_mgmt.h) ----
+    def init_const(self, ip, ntype, nbfp):
+        nbfp = np.ascontiguousarray(nbfp, dtype=np.float32)
+        assert nbfp.size == ntype * ntype * 2
+        self._chk(self.lib.nbnxn_hip_init_const_flat(self.h, ip.el_type, ip.rcoulomb, ip.rvdw, ip.rlist, ip.epsfac,
+                                                     ip.k_rf, ip.c_rf, ip.ewaldcoeff_q, ip.sh_ewald,
+                                                     ip.disp_cpot, ip.rep_cpot, ntype, abi.ptr(nbfp)))
+
+    def init_const_struct(self, ic, nbv_group):
+        self._chk(self.lib.nbnxn_hip_init_const(self.h, C.byref(ic), C.byref(nbv_group)))
+
+    def init_atomdata(self, natoms, natoms_local, ntype, type_):
+        type_ = np.ascontiguousarray(type_, dtype=np.int32)
+        assert len(type_) == natoms
+        self._chk(self.lib.nbnxn_hip_init_atomdata_flat(self.h, natoms, natoms_local, ntype, abi.ptr(type_)))
+        self.natoms = natoms
+
+    def init_atomdata_struct(self, nbat):
+        self._chk(self.lib.nbnxn_hip_init_atomdata(self.h, C.byref(nbat)))
+        self.natoms = nbat.natoms
+
+    def init_pairlist(self, pl, iloc=abi.LOCAL):
+        self._chk(self.lib.nbnxn_hip_init_pairlist_flat(self.h, iloc, pl.rlist, pl.nsci, abi.ptr(pl.sci), pl.ncj4,
+                                                        abi.ptr(pl.cj4), pl.nexcl, abi.ptr(pl.excl), pl.nci_tot))
+
+    def init_pairlist_struct(self, pl_struct_ptr, iloc=abi.LOCAL):
+        self._chk(self.lib.nbnxn_hip_init_pairlist(self.h, pl_struct_ptr, iloc))
+
+    def verify_pairlist(self, pl, iloc=abi.LOCAL):
+        n = self.lib.nbnxn_hip_verify_pairlist_flat(self.h, iloc, pl.nsci, abi.ptr(pl.sci), pl.ncj4, abi.ptr(pl.cj4),
+                                                    pl.nexcl, abi.ptr(pl.excl))
+        if n < 0:
+            raise HipError(self.lib.nbnxn_hip_last_error().decode())
+        return n
+
+    def download_cj4(self, pl, iloc=abi.LOCAL):
+        out = np.zeros(pl.ncj4, dtype=abi.cj4_dtype)
+        self._chk(self.lib.nbnxn_hip_download_cj4(self.h, iloc, pl.ncj4, abi.ptr(out)))
+        return out
+
+    def upload_shiftvec(self, shift_vec):
+        sv = np.ascontiguousarray(shift_vec, dtype=np.float32)
+        assert sv.size == abi.SHIFTS * 3
+        self._chk(self.lib.nbnxn_hip_upload_shiftvec_flat(self.h, abi.ptr(sv)))
+
+    def pme_loadbal_update_param(self, ic):
+        self._chk(self.lib.nbnxn_hip_pme_loadbal_update_param(self.h, C.byref(ic)))
+
+    def clear_outputs(self, flags):
+        self._chk(self.lib.nbnxn_hip_clear_outputs(self.h, flags))
+
+    def min_ci_balanced(self):
+        return self.lib.nbnxn_hip_min_ci_balanced(self.h)
+
+    def is_kernel_ewald_analytical(self):
+        return bool(self.lib.nbnxn_hip_is_kernel_ewald_analytical(self.h))
+
+    def timings(self):
+        p = self.lib.nbnxn_hip_get_timings(self.h)
+        return p.contents if p else None
+
+    def reset_timings(self):
+        self._chk(self.lib.nbnxn_hip_reset_timings(self.h))
+
+    def set_prune(self, iloc, on):
+        self._chk(self.lib.nbnxn_hip_set_prune(self.h, iloc, int(on)))
+
+    # ---- per step (nbnxn_cuda.h) ----
+    def launch_kernel(self, xq, flags, iloc=abi.LOCAL):
+        assert xq.dtype == np.float32 and xq.shape == (self.natoms, 4) and xq.flags.c_contiguous
+        self._keep["xq"] = xq
+        self._chk(self.lib.nbnxn_hip_launch_kernel_flat(self.h, abi.ptr(xq), flags, iloc))
+
+    def launch_kernel_resident(self, flags, iloc=abi.LOCAL):
+        self._chk(self.lib.nbnxn_hip_launch_kernel_resident(self.h, flags, iloc))
+
+    def launch_cpyback(self, f, flags, aloc=abi.LOCAL):
+        assert f.dtype == np.float32 and f.shape == (self.natoms, 3) and f.flags.c_contiguous
+        self._keep["f"] = f
+        self._chk(self.lib.nbnxn_hip_launch_cpyback_flat(self.h, abi.ptr(f), flags, aloc))
+
+    def wait_gpu(self, flags, aloc=abi.LOCAL, e_lj=None, e_el=None, fshift=None):
+        self._chk(self.lib.nbnxn_hip_wait_gpu_flat(self.h, flags, aloc, abi.ptr(e_lj), abi.ptr(e_el), abi.ptr(fshift)))
+
+    def read_outputs(self):
+        e = np.zeros(2, dtype=np.float32)
+        fs = np.zeros((abi.SHIFTS, 3), dtype=np.float32)
+        self._chk(self.lib.nbnxn_hip_read_outputs(self.h, abi.ptr(e[0:1]), abi.ptr(e[1:2]), abi.ptr(fs)))
+        return float(e[0]), float(e[1]), fs
+
+    def device_buffers(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.nbnxn_hip_get_device_buffers(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def stream(self, iloc=abi.LOCAL):
+        return self.lib.nbnxn_hip_get_stream(self.h, iloc)
+
+    def last_kernel_ms(self, iloc=abi.LOCAL):
+        return float(self.lib.nbnxn_hip_last_kernel_ms(self.h, iloc))
+
+    # ---- convenience: one full step as do_force_cutsVERLET issues it (sim_util.c:1012-1486) ----
+    def compute(self, xq, flags=0, iloc=abi.LOCAL):
+        """clear_outputs -> launch_kernel -> launch_cpyback -> wait_gpu.  Returns f, (e_lj, e_el, fshift)."""
+        f = np.zeros((self.natoms, 3), dtype=np.float32)
+        e_lj = np.zeros(1, dtype=np.float32)
+        e_el = np.zeros(1, dtype=np.float32)
+        fshift = np.zeros((abi.SHIFTS, 3), dtype=np.float32)
+        self.clear_outputs(flags | abi.FORCE_VIRIAL)
+        self.launch_kernel(xq, flags, iloc)
+        self.launch_cpyback(f, flags, iloc)
+        self.wait_gpu(flags, iloc, e_lj, e_el, fshift)
+        return f, (float(e_lj[0]), float(e_el[0]), fshift)
