@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- pair-interactions/s and nonbonded ns/day of the Verlet cluster-pair path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ewald|rf] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1: BASELINE.json configs[2], the configuration the metric is quoted on: SPC/E water,
+97,200 atoms (spc216 tiled 5x5x6), analytical Ewald real space + LJ, rc = rlist = 1.0 nm,
+energies + virial every step.  (--workload rf gives configs[1]: SPC, reaction field.)
+N > 1: weak scaling: N slabs of that box stacked along z (97,200 x N atoms), one rank per
+GPU, 1-D spatial domain decomposition with RCCL halo exchange (gromacs-cosmo_amd/dd.py).
+
+One step = clear outputs + nonbonded kernel (+ output fold) on coordinates and pair list
+already resident in HBM; the list was pruned by the first warm-up step, as it is once per
+list lifetime in the reference.  pair interactions = cluster pairs in the uploaded list x 64,
+the reference's counting convention (nbnxn_search.c:5770-5777), NOT the pruned count.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+if not os.path.exists(os.path.join(ROOT, "gromacs_cosmo_amd")):
+    os.symlink("gromacs-cosmo_amd", os.path.join(ROOT, "gromacs_cosmo_amd"))
+
+# flops per pair slot of the reference's cost model (gmxlib/nrnb.c:101-106)
+FLOPS = {("rf", False): 38, ("rf", True): 54, ("ewald", False): 66, ("ewald", True): 107}
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+DT_FS = 2.0
+
+
+def cpu_baseline(prep, ip, seconds=12.0):
+    """The reference's plain-C nbnxn_kernel_ref (oracle/_ref, compiled from the reference tree)
+    on the host cores, same atoms and pairs (as a 4x4 list); falls back to the repo's scalar
+    float port when oracle/_ref was not built.  Bounded sample: repeats for ~`seconds`."""
+    import oracle as O
+    if O.have_ref():
+        cores = max(1, min(16, os.cpu_count() or 1))
+        rk = O.RefKernelRef(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip, nlist=cores)
+        rk.run(calc_ener=False, nthreads=cores, outputs=False)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            rk.run(calc_ener=False, nthreads=cores, outputs=False)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds or n >= 200:
+                break
+        pairs = rk.ncj * 16      # its own list: 4x4 cluster pairs x 16
+        return {"value": pairs * n / dt, "unit": "pair/s", "cores": cores, "kind": "reference",
+                "sample": f"{n} force-only calls of nbnxn_kernel_ref (plain-C 4x4, {'tabulated Ewald' if ip.el_type else 'RF'}) "
+                          f"on the same {len(prep.xq)} atoms, {rk.ncj} 4x4 cluster pairs per call, {dt:.1f} s",
+                "ms_per_step": 1e3 * dt / n}
+    t0 = time.perf_counter()
+    O.kernel_gpu_list_f32(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
+    dt = time.perf_counter() - t0
+    return {"value": prep.pair_slots / dt, "unit": "pair/s", "cores": 1, "kind": "port",
+            "sample": f"1 force-only call of the scalar float port over the GPU list, {dt:.1f} s", "ms_per_step": 1e3 * dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="ewald", choices=["ewald", "rf"])
+    ap.add_argument("--force-only", action="store_true", help="F kernel instead of energies+virial every step")
+    ap.add_argument("--tiles", default="5,5,6")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="do not split list entries for load balance")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gromacs_cosmo_amd as g
+    from gromacs_cosmo_amd import abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    tiles = tuple(int(t) for t in args.tiles.split(","))
+    ener = not args.force_only
+    flags = abi.FORCE_VIRIAL if ener else 0
+    model = "spce" if args.workload == "ewald" else "spc"
+    ip = g.system.ewald(1.0) if args.workload == "ewald" else g.system.reaction_field(1.0)
+    flops_pair = FLOPS[(args.workload, ener)]
+
+    if world == 1:
+        system = g.system.water_box(*tiles, model=model)
+        nb = g.gpu.NbnxnHip(local_rank)
+        prep = g.workload.prepare(system, ip, 0 if args.no_split else nb.min_ci_balanced())
+        g.workload.upload(nb, prep, ip)
+        assert nb.verify_pairlist(prep.pl) == 0
+        natoms = system.natoms
+        pair_slots = prep.pair_slots
+        # coordinates resident in HBM; this first call also prunes the fresh list
+        f0, _ = nb.compute(prep.xq, flags)
+
+        def step():
+            nb.clear_outputs(flags)
+            nb.launch_kernel_resident(flags)
+        stream = torch.cuda.ExternalStream(nb.stream(abi.LOCAL))
+        sync = lambda: torch.cuda.synchronize()
+        parallelism = "1 GPU"
+        cfg_extra = {"nsci": prep.pl.nsci, "ncj4": prep.pl.ncj4, "cluster_pairs": prep.pl.nci_tot}
+    else:
+        from gromacs_cosmo_amd import dd
+        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags)
+        natoms = run.natoms_global
+        pair_slots = run.pair_slots_local    # summed over ranks below
+        step = run.step
+        stream = torch.cuda.ExternalStream(run.nb.stream(abi.LOCAL))
+        sync = lambda: torch.cuda.synchronize()
+        parallelism = f"dd{world} (z slabs, RCCL halo x/f)"
+        cfg_extra = run.describe()
+        run.step()   # prunes
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    sync()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # per-step device time on the kernel's stream
+
+    if world > 1:
+        t = torch.tensor([wall, float(pair_slots), kernel_ms], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        wall = float(tmax[0])
+        pair_slots = float(tsum[1])
+        kernel_ms = float(tmax[2])
+
+    if rank == 0:
+        ms_per_step = 1e3 * wall / args.steps
+        value = pair_slots * args.steps / wall
+        achieved_tflops = pair_slots / world * flops_pair / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "pair interactions/s (cluster pairs x 64 per step, nonbonded Verlet kernel)",
+            "value": value, "unit": "pair/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ns_per_day": 86400.0 * DT_FS * 1e-6 / (ms_per_step * 1e-3),
+            "ns_per_day_note": f"nonbonded only, dt = {DT_FS} fs",
+            "config": dict({"workload": f"{model.upper()} water {natoms} atoms ({'x'.join(map(str, tiles))} spc216 tiles"
+                                        f"{' per GPU' if world > 1 else ''}), "
+                                        f"{'analytical Ewald real-space' if args.workload == 'ewald' else 'reaction-field'} + LJ, "
+                                        f"rc=rlist=1.0 nm, {'energies+virial every step' if ener else 'forces only'}",
+                            "parallelism": parallelism, "pair_slots_per_step": pair_slots,
+                            "flops_per_pair": flops_pair}, **cfg_extra),
+            "roofline": {"bound": "fp32-vector", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms,
+                         "note": "algorithmic flops = pair slots x nrnb.c cost; duration = mean HIP-event time per step on the kernel stream"},
+        }
+        if not args.no_cpu and world == 1:
+            cb = cpu_baseline(prep, ip)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

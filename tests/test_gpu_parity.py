@@ -1,0 +1,213 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden
+vectors.  Forces within 1e-5 relative RMS, energies and virial within 1e-5 relative
+(BASELINE.json north_star); list upload and pruning bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gromacs_cosmo_amd as g
+from gromacs_cosmo_amd import abi
+import oracle as O
+from util import SMALL, LARGE, FORCE_RTOL, ENERGY_RTOL, relrms, load_small, load_large, virial_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nb():
+    h = g.gpu.NbnxnHip(0)
+    yield h
+    h.close()
+
+
+def _upload(nb, p, ip):
+    g.workload.upload(nb, p, ip)
+    assert nb.verify_pairlist(p.pl) == 0          # bit-exact upload (north_star)
+
+
+def _check_against(f, e, p, ip, o, d=None):
+    elj, eel, fsh = e
+    assert relrms(f, o["f"]) < FORCE_RTOL
+    assert abs(elj - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"])
+    assert abs(eel - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"])
+    fsh_o = o["fshift"].copy()
+    fsh_o[abi.CENTRAL] = 0                         # the GPU path skips the central shift (virial-neutral)
+    vir = virial_from(p.xq, f, p.shift_vec, fsh)
+    vir_o = virial_from(p.xq, o["f"], p.shift_vec, fsh_o)
+    assert np.abs(vir - vir_o).max() < ENERGY_RTOL * np.abs(vir_o).max()
+    if d is not None:
+        assert relrms(f, d["ref_f"]) < FORCE_RTOL          # the reference's nbnxn_kernel_ref
+        assert relrms(f, d["gpuref_f"]) < FORCE_RTOL       # the reference's nbnxn_kernel_gpu_ref
+        assert abs(eel - d["gpuref_Vc"]) < 2e-5 * abs(d["gpuref_Vc"])
+        assert abs(elj - d["gpuref_Vvdw"]) < 2e-5 * abs(d["gpuref_Vvdw"])
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_parity_small_fixtures(nb, name):
+    p, ip, d = load_small(name)
+    _upload(nb, p, ip)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    # 1st call after init_pairlist: energy + prune flavour
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    _check_against(f, e, p, ip, o, d)
+    # pruning is bit-exact against the CPU rule and leaves the physics alone
+    cj4 = nb.download_cj4(p.pl)
+    assert np.array_equal(cj4["imei"]["imask"], O.prune_list(p.xq, p.shift_vec, p.pl, ip.rlist)["imei"]["imask"])
+    # force-only flavour on the pruned list
+    f2, e2 = nb.compute(p.xq, 0)
+    assert relrms(f2, o["f"]) < FORCE_RTOL
+    assert e2[0] == 0 and e2[1] == 0 and not e2[2].any()   # no energies/fshift without GMX_FORCE_VIRIAL
+    # energy flavour without pruning
+    f3, e3 = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    _check_against(f3, e3, p, ip, o, d)
+    # force-only + prune flavour
+    nb.init_pairlist(p.pl)
+    f4, _ = nb.compute(p.xq, 0)
+    assert relrms(f4, o["f"]) < FORCE_RTOL
+    assert np.array_equal(nb.download_cj4(p.pl)["imei"]["imask"], cj4["imei"]["imask"])
+
+
+@pytest.mark.parametrize("name", LARGE)
+def test_parity_97k_against_reference_samples(nb, name):
+    system, ip, d = load_large(name)
+    p = g.workload.prepare(system, ip, nb.min_ci_balanced())
+    _upload(nb, p, ip)
+    f, (elj, eel, fsh) = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    stride = int(d["stride"])
+    assert relrms(f[::stride], d["ref_f_sample"]) < FORCE_RTOL
+    assert relrms(f[::stride], d["gpuref_f_sample"]) < FORCE_RTOL
+    assert abs(np.sqrt((f.astype(np.float64) ** 2).sum()) - float(d["ref_f_norm"])) < 1e-5 * float(d["ref_f_norm"])
+    assert abs(eel - d["gpuref_Vc"]) < 2e-5 * abs(d["gpuref_Vc"])
+    assert abs(elj - d["gpuref_Vvdw"]) < 2e-5 * abs(d["gpuref_Vvdw"])
+    # full-size check against the double-precision oracle (a few seconds on the host)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    _check_against(f, (elj, eel, fsh), p, ip, o)
+    # size-independent properties: Newton's third law and idempotence of repeated steps
+    assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-3 * np.abs(f).max()
+    f2, _ = nb.compute(p.xq, 0)
+    assert relrms(f2, f) < 2e-6                     # only the fp32 atomic order differs
+
+
+def test_struct_entry_points_take_reference_layout_objects(nb):
+    """The struct-taking calls (what sim_util.c / forcerec.c would call) with ctypes mirrors of
+    nbnxn_atomdata_t, nbnxn_pairlist_t, interaction_const_t, nonbonded_verlet_group_t."""
+    s = g.system.water_box(5, 1, 1)
+    ip = g.system.ewald(0.9)
+    p = g.workload.prepare(s, ip)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    f = np.zeros((p.natoms, 3), dtype=np.float32)
+    nbfp = np.ascontiguousarray(p.nbfp, dtype=np.float32)
+    out = abi.AtomdataOutput()
+    out.f = abi.ptr(f)
+    nbat = abi.Atomdata()
+    nbat.ntype = p.ntype
+    nbat.nbfp = abi.ptr(nbfp)
+    nbat.natoms = p.natoms
+    nbat.natoms_local = p.natoms
+    nbat.type = abi.ptr(p.type)
+    nbat.XFormat, nbat.FFormat = 1, 0           # nbatXYZQ, nbatXYZ
+    nbat.na_c = 8
+    nbat.nenergrp = 1
+    nbat.bDynamicBox = 0
+    nbat.shift_vec = abi.ptr(p.shift_vec)
+    nbat.xstride, nbat.fstride = 4, 3
+    nbat.x = abi.ptr(p.xq)
+    nbat.nout = 1
+    nbat.out = C.pointer(out)
+    grp = abi.VerletGroup()
+    grp.nbat = C.pointer(nbat)
+    ic = ip.to_struct()
+    lib = nb.lib
+    chk = nb._chk
+    chk(lib.nbnxn_hip_init_const(nb.h, C.byref(ic), C.byref(grp)))
+    chk(lib.nbnxn_hip_init_atomdata(nb.h, C.byref(nbat)))
+    nb.natoms = p.natoms
+    chk(lib.nbnxn_hip_upload_shiftvec(nb.h, C.byref(nbat)))
+    chk(lib.nbnxn_hip_init_pairlist(nb.h, p.host.pairlist_struct(abi.LOCAL), abi.LOCAL))
+    assert nb.is_kernel_ewald_analytical()
+    chk(lib.nbnxn_hip_clear_outputs(nb.h, abi.FORCE_VIRIAL))
+    chk(lib.nbnxn_hip_launch_kernel(nb.h, C.byref(nbat), abi.FORCE_VIRIAL, abi.LOCAL))
+    chk(lib.nbnxn_hip_launch_cpyback(nb.h, C.byref(nbat), abi.FORCE_VIRIAL, abi.LOCAL))
+    e_lj, e_el = np.full(1, 10.0, np.float32), np.full(1, -20.0, np.float32)
+    fsh = np.zeros((45, 3), dtype=np.float32)
+    chk(lib.nbnxn_hip_wait_gpu(nb.h, C.byref(nbat), abi.FORCE_VIRIAL, abi.LOCAL, abi.ptr(e_lj), abi.ptr(e_el), abi.ptr(fsh)))
+    assert relrms(f, o["f"]) < FORCE_RTOL
+    # wait_gpu ADDS into the caller's accumulators (nbnxn_cuda.cu:662-680)
+    assert abs((e_lj[0] - 10.0) - o["Vvdw"]) < 2e-5 * abs(o["Vvdw"])
+    assert abs((e_el[0] + 20.0) - o["Vc"]) < 2e-5 * abs(o["Vc"])
+    t = nb.timings()
+    assert t is not None and t.nb_c >= 1 and t.ktime[1][1].c >= 1 and t.ktime[1][1].t > 0
+
+
+def test_resident_path_matches_host_path(nb):
+    p, ip, d = load_small("spc3240_rf09")
+    _upload(nb, p, ip)
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)       # uploads xq, prunes
+    nb.clear_outputs(abi.FORCE_VIRIAL)
+    nb.launch_kernel_resident(abi.FORCE_VIRIAL)     # coordinates already in HBM
+    f2 = np.zeros_like(f)
+    nb.launch_cpyback(f2, abi.FORCE_VIRIAL)
+    nb.wait_gpu(abi.FORCE_VIRIAL)
+    elj, eel, fsh = nb.read_outputs()
+    assert relrms(f2, f) < 2e-6
+    assert abs(elj - e[0]) < 1e-6 * abs(e[0]) and abs(eel - e[1]) < 1e-6 * abs(e[1])
+    assert nb.last_kernel_ms() > 0
+
+
+def test_empty_and_ragged_inputs(nb):
+    p, ip, d = load_small("spc216_rf09")
+    _upload(nb, p, ip)
+    # an empty list is a no-op (nbnxn_cuda.cu:305-309)
+    from gromacs_cosmo_amd.host import PairList
+    empty = PairList(p.pl.sci[:0], p.pl.cj4[:0], p.pl.excl[:1], 0, ip.rlist)
+    nb.init_pairlist(empty)
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert not f.any() and e[0] == 0 and e[1] == 0
+    # a list whose every interaction mask is zero: entries are walked, nothing is computed
+    cj4 = p.pl.cj4.copy()
+    cj4["imei"]["imask"][:] = 0
+    nb.init_pairlist(PairList(p.pl.sci, cj4, p.pl.excl, 0, ip.rlist))
+    f, e = nb.compute(p.xq, 0)
+    assert not f.any()
+    # one entry only (ragged tail of the grid: the last super-cluster is mostly fillers)
+    last = p.pl.sci[np.argmax(p.pl.sci["sci"])][None].copy()
+    one = PairList(last, p.pl.cj4, p.pl.excl, 0, ip.rlist)
+    nb.init_pairlist(one)
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, one, ip)
+    assert relrms(f, o["f"]) < FORCE_RTOL
+
+
+def test_bad_inputs_fail_loudly_before_any_launch(nb):
+    p, ip, d = load_small("spc216_rf09")
+    _upload(nb, p, ip)
+    bad = p.pl.cj4.copy()
+    bad["cj"][0, 0] = 10 ** 6                      # j-cluster outside the atom arrays
+    from gromacs_cosmo_amd.host import PairList
+    with pytest.raises(g.gpu.HipError):
+        nb.init_pairlist(PairList(p.pl.sci, bad, p.pl.excl, p.pl.nci_tot, ip.rlist))
+    bad = p.pl.cj4.copy()
+    bad["imei"]["excl_ind"][0, 0] = p.pl.nexcl     # exclusion index out of range
+    with pytest.raises(g.gpu.HipError):
+        nb.init_pairlist(PairList(p.pl.sci, bad, p.pl.excl, p.pl.nci_tot, ip.rlist))
+    with pytest.raises(g.gpu.HipError):
+        nb.init_atomdata(100, 100, p.ntype, p.type[:100])   # not a multiple of 64
+    ip2 = g.system.reaction_field(0.9)
+    ip2.rvdw = 0.8
+    with pytest.raises(g.gpu.HipError):
+        nb.init_const(ip2, p.ntype, p.nbfp)        # twin-range flavour not built
+    with pytest.raises(g.gpu.HipError):
+        nb.wait_gpu(0, aloc=2)                     # eatAll is not valid here (nbnxn_cuda.cu:568-574)
+
+
+def test_many_atom_types_use_the_global_lj_table(nb):
+    s = g.system.lj_chain_mixture(1200, ntype=20, seed=3)   # 21 types > 16: table stays in L2
+    ip = g.system.reaction_field(0.8, epsilon_rf=0.0)
+    p = g.workload.prepare(s, ip)
+    _upload(nb, p, ip)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert relrms(f, o["f"]) < FORCE_RTOL
+    assert abs(e[0] - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"])
+    assert abs(e[1] - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"])

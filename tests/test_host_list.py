@@ -1,0 +1,160 @@
+"""CPU: the host-side producers (gridding, atom data, GPU-format list) against the format
+rules of the reference (types/nbnxn_pairlist.h:102-123, nbnxn_search.c) and its measured list
+statistics."""
+import numpy as np
+import pytest
+
+import gromacs_cosmo_amd as g
+from gromacs_cosmo_amd import abi
+import oracle as O
+from util import relrms
+
+
+def test_grid_is_a_permutation_with_far_away_fillers():
+    s = g.system.water_box(2, 2, 2)
+    ip = g.system.reaction_field(0.9)
+    p = g.workload.prepare(s, ip)
+    a = p.host.atom_order()
+    cell = p.host.cell_index()
+    assert len(a) % 64 == 0
+    real = a[a >= 0]
+    assert sorted(real.tolist()) == list(range(s.natoms))
+    assert np.array_equal(a[cell], np.arange(s.natoms))
+    # real atoms carry their coordinates, charge and type; fillers sit beyond -107 nm with q = 0
+    assert np.array_equal(p.xq[cell, :3], s.x)
+    assert np.array_equal(p.xq[cell, 3], s.q)
+    assert np.array_equal(p.type[cell], s.type)
+    fill = a < 0
+    assert (p.xq[fill, :3] <= -107.0).all() and (p.xq[fill, 3] == 0).all() and (p.type[fill] == p.ntype - 1).all()
+    # fillers only at the end of a column's last super-cluster: distinct positions
+    assert len(np.unique(p.xq[fill, :3], axis=0)) == fill.sum()
+
+
+def test_shift_vectors_follow_ishift_ordering():
+    s = g.system.water_box(2, 2, 2)
+    h = g.host.NbnxnHost(s.box)
+    sv = h.shift_vec()
+    assert sv.shape == (45, 3)
+    assert (sv[abi.CENTRAL] == 0).all()
+    # XYZ2IS(x,y,z) = 5*(3*(z+1)+(y+1))+x+2  (types/ishift.h:45-55)
+    for tz in (-1, 0, 1):
+        for ty in (-1, 0, 1):
+            for tx in (-2, -1, 0, 1, 2):
+                i = 5 * (3 * (tz + 1) + ty + 1) + tx + 2
+                assert np.allclose(sv[i], np.array([tx, ty, tz]) * s.box)
+
+
+def _check_list_invariants(p):
+    pl = p.pl
+    ncl = p.natoms // 8
+    assert (pl.excl["pair"][0] == 0xffffffff).all()             # shared "no exclusion" entry
+    assert (pl.sci["shift"] <= abi.CENTRAL).all()               # one-way lists: backward shifts only
+    lens = pl.sci["cj4_ind_end"] - pl.sci["cj4_ind_start"]
+    assert (lens > 0).all()
+    m = 2 * pl.ncj4 // pl.nsci
+    assert (np.diff(np.minimum(lens, m)) <= 0).all()            # sort_sci: descending, clipped at 2x mean
+    used = np.zeros(pl.ncj4, dtype=int)
+    for e in pl.sci:
+        used[e["cj4_ind_start"]:e["cj4_ind_end"]] += 1
+    assert (used == 1).all()                                    # every cj4 belongs to exactly one entry
+    assert (pl.cj4["imei"]["imask"][:, 0] == pl.cj4["imei"]["imask"][:, 1]).all()
+    nbits = sum(bin(int(x)).count("1") for x in pl.cj4["imei"]["imask"][:, 0])
+    assert nbits == pl.nci_tot
+    ei = pl.cj4["imei"]["excl_ind"]
+    assert ei.min() >= 0 and ei.max() < pl.nexcl
+    nz = ei[ei > 0]
+    assert len(np.unique(nz)) == len(nz)                        # private exclusion words are not shared
+    for c in pl.cj4:
+        msk = int(c["imei"]["imask"][0])
+        for jm in range(4):
+            if (msk >> (8 * jm)) & 0xff:
+                assert 0 <= c["cj"][jm] < ncl
+    # half list: CENTRAL entries only hold j-clusters of super-clusters >= their own
+    for e in pl.sci:
+        if e["shift"] == abi.CENTRAL:
+            cjs = pl.cj4["cj"][e["cj4_ind_start"]:e["cj4_ind_end"]]
+            msk = pl.cj4["imei"]["imask"][e["cj4_ind_start"]:e["cj4_ind_end"], 0]
+            for row, mk in zip(cjs, msk):
+                for jm in range(4):
+                    if (int(mk) >> (8 * jm)) & 0xff:
+                        assert row[jm] >= e["sci"] * 8
+
+
+@pytest.mark.parametrize("mcb", [0, 300])
+def test_list_invariants_and_completeness(mcb):
+    s = g.system.water_box(2, 2, 2)
+    ip = g.system.reaction_field(0.9)
+    p = g.workload.prepare(s, ip, mcb)
+    _check_list_invariants(p)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    b = O.brute_force(s.x, s.q, s.type, p.ntype, p.nbfp, s.box, s.excl_index, s.excl_a, ip)
+    fb = np.zeros_like(o["f"])
+    fb[p.host.cell_index()] = b["f"]
+    assert relrms(o["f"], fb) < 1e-12
+    assert abs(o["Vc"] - b["Vc"]) < 1e-10 * abs(b["Vc"])
+    assert abs(o["Vvdw"] - b["Vvdw"]) < 1e-10 * abs(b["Vvdw"])
+
+
+def test_splitting_makes_more_entries_but_the_same_pairs():
+    s = g.system.water_box(3, 3, 3)
+    ip = g.system.ewald(0.9)
+    p0 = g.workload.prepare(s, ip, 0)
+    p1 = g.workload.prepare(s, ip, 2000)
+    assert p1.pl.nsci > 2 * p0.pl.nsci
+    assert p1.pl.nci_tot == p0.pl.nci_tot and p1.pl.ncj4 == p0.pl.ncj4
+    o0 = O.kernel_gpu_list(p0.xq, p0.type, p0.ntype, p0.nbfp, p0.shift_vec, p0.pl, ip)
+    o1 = O.kernel_gpu_list(p1.xq, p1.type, p1.ntype, p1.nbfp, p1.shift_vec, p1.pl, ip)
+    assert relrms(o1["f"], o0["f"]) < 1e-13 and abs(o1["Vc"] - o0["Vc"]) < 1e-12 * abs(o0["Vc"])
+
+
+def test_exclusion_dense_mixture_is_complete():
+    s = g.system.lj_chain_mixture(1500, ntype=5, seed=7)
+    ip = g.system.reaction_field(0.8, epsilon_rf=0.0)
+    p = g.workload.prepare(s, ip)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    b = O.brute_force(s.x, s.q, s.type, p.ntype, p.nbfp, s.box, s.excl_index, s.excl_a, ip)
+    fb = np.zeros_like(o["f"])
+    fb[p.host.cell_index()] = b["f"]
+    assert relrms(o["f"], fb) < 1e-12
+    assert abs(o["Vc"] - b["Vc"]) < 1e-10 * abs(b["Vc"])
+
+
+def test_list_statistics_match_the_reference_at_97k():
+    """the reference's own list for this system (5x5x6 spc216, rlist 1.0) has 1570
+    super-clusters, nsci 2593, ncj4 53,638, 1,042,421 cluster pairs, nexcl 15,786.  Our builder
+    sorts ties differently, so the numbers agree to a few percent, not exactly."""
+    s = g.system.water_box(5, 5, 6)
+    ip = g.system.reaction_field(1.0)
+    p = g.workload.prepare(s, ip)
+    assert p.host.ncolumns() == (10, 10)
+    st = p.pl.stats()
+    assert abs(p.natoms // 64 - 1570) < 0.03 * 1570
+    assert abs(st["nsci"] - 2593) < 0.03 * 2593
+    assert abs(st["ncj4"] - 53638) < 0.03 * 53638
+    assert abs(st["nci_tot"] - 1042421) < 0.03 * 1042421
+    assert abs(st["nexcl"] - 15786) < 0.10 * 15786
+
+
+def test_add_f_scatters_back_to_caller_order():
+    s = g.system.water_box(1, 1, 1)
+    ip = g.system.reaction_field(0.9)
+    p = g.workload.prepare(s, ip)
+    rng = np.random.default_rng(1)
+    fnb = rng.standard_normal((p.natoms, 3)).astype(np.float32)
+    f = np.ones((s.natoms, 3), dtype=np.float32)
+    p.host.add_f(fnb, f)
+    assert np.array_equal(f, 1 + fnb[p.host.cell_index()])
+
+
+def test_errors_are_reported_not_crashed():
+    s = g.system.water_box(1, 1, 1)
+    h = g.host.NbnxnHost(s.box)
+    with pytest.raises(g.host.HostError):
+        h.make_pairlist(abi.LOCAL, 0.9, np.zeros((64, 4), np.float32))   # no grid yet
+    h.put_on_grid(0, (0, 0, 0), s.box, 0, s.x)
+    xq, typ = h.set_atomdata(3, s.type, s.q)
+    h.copy_x_to_xq(s.x, xq)
+    with pytest.raises(g.host.HostError):
+        h.make_pairlist(abi.LOCAL, 1.0, xq)   # box shorter than 2*rlist
+    with pytest.raises(g.host.HostError):
+        h.set_atomdata(3, s.type + 5, s.q)    # type outside the table
