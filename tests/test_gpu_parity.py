@@ -109,7 +109,7 @@ def test_struct_entry_points_take_reference_layout_objects(nb):
     nbat.XFormat, nbat.FFormat = 1, 0           # nbatXYZQ, nbatXYZ
     nbat.na_c = 8
     nbat.nenergrp = 1
-    nbat.bDynamicBox = 0
+    nbat.bDynamicBox = 1           # the shared handle has seen other boxes: force the shift-vector upload
     nbat.shift_vec = abi.ptr(p.shift_vec)
     nbat.xstride, nbat.fstride = 4, 3
     nbat.x = abi.ptr(p.xq)
