@@ -329,7 +329,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.partial = pl.partial.p;
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
-    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, st));
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->variant, st));
     if (ener)
     {
         HIP_TRY(nbx_launch_reduce_outputs(pl.partial.p, pl.nsci, nb->fshift, nb->e_lj, nb->e_el, st));
@@ -815,6 +815,16 @@ float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc)
     if (!nb || iloc < 0 || iloc > 1 || !nb->do_time || !nb->k_timed[iloc]) { return -1.0f; }
     if (hipEventSynchronize(nb->k_stop[iloc]) != hipSuccess) { return -1.0f; }
     return elapsed(nb->k_start[iloc], nb->k_stop[iloc]);
+}
+
+// diagnostic helper (not in the public header): raw copy of the per-entry partial records
+int nbnxn_hip_debug_read_partial(nbnxn_hip_ptr_t nb, int iloc, void *buf, size_t nbytes)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    HIP_TRY(hipDeviceSynchronize());
+    if (nbytes > nb->plist[iloc].partial.alloc * sizeof(float)) { return nbx_fail("partial buffer is smaller"); }
+    HIP_TRY(hipMemcpy(buf, nb->plist[iloc].partial.p, nbytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)

@@ -38,7 +38,7 @@ struct nbx_kernel_args_t {
 };
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
-                                hipStream_t stream);
+                                int variant, hipStream_t stream);
 
 hipError_t nbx_launch_reduce_outputs(const float *partial, int nsci, float *fshift, float *e_lj, float *e_el,
                                      hipStream_t stream);

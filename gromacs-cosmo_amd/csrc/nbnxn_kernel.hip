@@ -79,6 +79,30 @@ __device__ __forceinline__ float wave_sum(float v)
 
 constexpr int MAX_LDS_TYPES = NBX_KERNEL_MAX_LDS_TYPES;
 
+// j-forces are not sent to memory one cluster at a time: on CDNA the wave's loads, stores
+// and atomics retire in order through one counter (vmcnt), so a load issued after an atomic
+// cannot be waited for without also waiting for that atomic's round trip to the memory side
+// (~1-3 us under load).  The reduced j-forces of up to FJ_CAP clusters are parked in LDS and
+// flushed as full 64-lane atomic instructions; the kernel's loads then only wait for loads.
+template <int FJ_CAP>
+__device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int *s_fjc, int n, int lane)
+{
+    __syncthreads();
+    for (int idx = lane; idx < n * 24; idx += 64)
+    {
+        const int cl   = (idx * 2731) >> 16;   // idx / 24 for idx < 4096
+        const int comp = idx - cl * 24;
+        atomicAdd(&f[s_fjc[cl] * 24 + comp], s_fj[idx]);
+    }
+    __syncthreads();
+}
+
+
+
+#ifndef NBX_V2_WAVES
+#define NBX_V2_WAVES 3
+#endif
+
 template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
 __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
 {
@@ -90,6 +114,10 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
     __shared__ int    s_ti[64];
     __shared__ float  s_red[192];
     __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
+    constexpr int     FJ_CAP = 16;
+    __shared__ float  s_fj[FJ_CAP * 24];
+    __shared__ int    s_fjc[FJ_CAP];
+    int               nfj = 0;
 
     const nbx_sci_t e     = a.sci[blockIdx.x];
     const int       sci   = e.sci;
@@ -211,7 +239,9 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
             // 96 contiguous bytes, one atomic instruction
             fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
             const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
-            if (tidxi < 3) { atomicAdd(&a.f[aj * 3 + tidxi], fj); }
+            if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
+            if (lane == 0) { s_fjc[nfj] = cj; }
+            nfj++;
         }
 
         if (PRUNE)
@@ -222,7 +252,9 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
                 a.cj4[j4].imei[1].imask = imask;
             }
         }
+        if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
     }
+    if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
 
     // i-forces: reduce-scatter over the 8 j-lanes (lane bits 5,4,3); lane (j,i) ends up
     // with the total of i-cluster j, atom i, i.e. of atom sci*64 + lane
@@ -278,6 +310,300 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Variant 2: i-atoms live in registers for the whole entry (each lane only ever touches
+// the 8 i-atoms {8*ci + iatom}), the cut-off is applied by select instead of a divergent
+// branch, cj4 groups without exclusion words take a path with no interaction-bit
+// arithmetic, and the four j-clusters of a cj4 group are fetched in one batch.
+// ---------------------------------------------------------------------------------------
+template <int EL, bool ENER, bool PRUNE, bool EXCL>
+__device__ __forceinline__ void pair_v2(const nbx_kernel_args_t &a, const float4 xi, const float4 xj,
+                                        const float2 c, const unsigned ebit, const bool allowed,
+                                        float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
+                                        float &E_lj, float &E_el, bool &any_in_rlist)
+{
+    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+    float       r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (PRUNE) { any_in_rlist = __any(r2 < a.rlist2); }
+    bool cond = r2 < a.rc2;
+    if (EXCL) { cond = cond && allowed; }
+    float int_bit = 1.0f;
+    if (EXCL)
+    {
+        int_bit = ebit ? 1.0f : 0.0f;
+        r2      = fmaf(1.0f - int_bit, NBX_AVOID_SING_R2_INC, r2);
+    }
+    const float inv_r  = __builtin_amdgcn_rsqf(r2);
+    const float inv_r2 = inv_r * inv_r;
+    float       inv_r6 = inv_r2 * inv_r2 * inv_r2;
+    if (EXCL) { inv_r6 *= int_bit; }
+    float       F  = inv_r6 * fmaf(c.y, inv_r6, -c.x) * inv_r2;
+    const float qq = xi.w * xj.w;
+    const float inv_r3 = EXCL ? int_bit * inv_r2 * inv_r : inv_r2 * inv_r;
+    if (EL == NBX_EL_RF) { F = fmaf(qq, inv_r3 - a.two_k_rf, F); }
+    else { F = fmaf(qq, fmaf(pme_corr_f(a.beta2 * r2), a.beta3, inv_r3), F); }
+    F = cond ? F : 0.0f;
+    if (ENER)
+    {
+        float elj = c.y * fmaf(inv_r6, inv_r6, a.rep_cpot) * (1.0f / 12.0f) - c.x * (inv_r6 + a.disp_cpot) * (1.0f / 6.0f);
+        float eel;
+        if (EL == NBX_EL_RF)
+        {
+            eel = qq * ((EXCL ? int_bit * inv_r : inv_r) + 0.5f * a.two_k_rf * r2 - a.c_rf);
+        }
+        else
+        {
+            const float er = erff(r2 * inv_r * a.beta);
+            eel = EXCL ? qq * (inv_r * (int_bit - er) - int_bit * a.sh_ewald) : qq * (inv_r * (1.0f - er) - a.sh_ewald);
+        }
+        if (EXCL) { elj *= int_bit; }
+        E_lj += cond ? elj : 0.0f;
+        E_el += cond ? eel : 0.0f;
+    }
+    fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
+    fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
+}
+
+// one cj4 group as a wave holds it: the four j-atoms of this lane, the lane's exclusion
+// word, and the wave-uniform list fields
+struct nbx_jbatch_t {
+    float4   xj[4];
+    int      tj[4];
+    unsigned wexcl;
+    unsigned imask;
+    int      cj[4];
+    bool     has_excl;
+};
+
+__device__ __forceinline__ void load_jbatch(const nbx_kernel_args_t &a, int j4, int lane, int tidxj, nbx_jbatch_t &b)
+{
+    const nbx_cj4_t *g = a.cj4 + j4;
+    b.imask = g->imei[0].imask | g->imei[1].imask;
+    const int ei0 = g->imei[0].excl_ind, ei1 = g->imei[1].excl_ind;
+    b.has_excl = (ei0 | ei1) != 0;
+    b.wexcl = 0xffffffffu;
+    if (b.has_excl) { b.wexcl = a.excl[lane < 32 ? ei0 : ei1].pair[lane & 31]; }
+#pragma unroll
+    for (int jm = 0; jm < 4; jm++)
+    {
+        // slots without interaction bits hold undefined j-clusters: read cluster 0 instead
+        b.cj[jm] = (b.imask >> (8 * jm)) & 0xffu ? g->cj[jm] : 0;
+        b.xj[jm] = a.xq[b.cj[jm] * 8 + tidxj];
+        b.tj[jm] = a.type[b.cj[jm] * 8 + tidxj];
+    }
+}
+
+template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_WAVES, 8))) nbnxn_kernel_v2(const nbx_kernel_args_t a)
+{
+    const int lane  = threadIdx.x;
+    const int tidxi = lane & 7;
+    const int tidxj = lane >> 3;
+
+    __shared__ float4 s_xqi[64];
+    __shared__ int    s_ti[64];
+    __shared__ float  s_red[192];
+    // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
+    __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
+    constexpr int     FJ_CAP = 64;
+    __shared__ float  s_fj[FJ_CAP * 24];
+    __shared__ int    s_fjc[FJ_CAP];
+    int               nfj = 0;
+
+    const nbx_sci_t e     = a.sci[blockIdx.x];
+    const int       sci   = e.sci;
+    const int       ntype = a.ntype;
+    const bool      central = (e.shift == NBX_CENTRAL);
+
+#ifdef NBX_STAMPS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    nbx_jbatch_t cur;
+    if (e.cj4_ind_start < e.cj4_ind_end) { load_jbatch(a, e.cj4_ind_start, lane, tidxj, cur); }
+
+    {
+        const int ai = sci * 64 + lane;
+        float4    x  = a.xq[ai];
+        x.x += a.shift_vec[3 * e.shift + 0];
+        x.y += a.shift_vec[3 * e.shift + 1];
+        x.z += a.shift_vec[3 * e.shift + 2];
+        x.w *= a.epsfac;
+        s_xqi[lane] = x;
+        s_ti[lane]  = a.type[ai];
+        if (NBFP_LDS)
+        {
+            for (int k = lane; k < ntype * ntype; k += 64)
+            {
+                const int t_i = k / ntype, t_j = k - t_i * ntype;
+                s_nbfp[t_j * MAX_LDS_TYPES + t_i] = a.nbfp[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
+    // their types are packed one per byte (LDS path: as byte offsets type*8 into a table row)
+    float4   xi[8];
+    unsigned tlo = 0, thi = 0;
+    float    fix[8], fiy[8], fiz[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        xi[i] = s_xqi[i * 8 + tidxi];
+        const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? 8u : 1u);
+        if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
+        fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
+    }
+
+    float E_lj = 0, E_el = 0;
+    if (ENER)
+    {
+        if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
+        {
+            const float q  = s_xqi[lane].w;
+            const float q2 = q * q * a.inv_epsfac;
+            E_el = (EL == NBX_EL_RF) ? -0.5f * a.c_rf * q2 : -a.beta * 0.564189583547756f * q2;
+        }
+    }
+
+    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
+    {
+        // software pipeline: the next group's list words and j-atoms are requested before
+        // this group's arithmetic starts
+        nbx_jbatch_t nxt;
+        if (j4 + 1 < e.cj4_ind_end) { load_jbatch(a, j4 + 1, lane, tidxj, nxt); }
+
+        unsigned imask = cur.imask;
+#pragma unroll
+        for (int jm = 0; jm < 4; jm++)
+        {
+            if (!(imask & (0xffu << (jm * 8)))) { continue; }
+            const int   cj  = cur.cj[jm];
+            const char *row = reinterpret_cast<const char *>(s_nbfp) + cur.tj[jm] * (MAX_LDS_TYPES * 8);
+            float       fjx = 0, fjy = 0, fjz = 0;
+#define NBX_LJ_PARAMS(i)                                                                              \
+    const unsigned tb_ = (((i) < 4 ? tlo : thi) >> (8 * ((i)&3))) & 0xffu;                             \
+    const float2   c   = NBFP_LDS ? *reinterpret_cast<const float2 *>(row + tb_) : a.nbfp[tb_ * ntype + cur.tj[jm]];
+            if (cur.has_excl)
+            {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    const unsigned bit = 1u << (jm * 8 + i);
+                    if (imask & bit)
+                    {
+                        NBX_LJ_PARAMS(i)
+                        const bool diag = central && (cj == sci * 8 + i);
+                        bool       any = true;
+                        pair_v2<EL, ENER, PRUNE, true>(a, xi[i], cur.xj[jm], c, cur.wexcl & bit, !diag || tidxj > tidxi,
+                                                       fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
+                        if (PRUNE && !any) { imask &= ~bit; }
+                    }
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    const unsigned bit = 1u << (jm * 8 + i);
+                    if (imask & bit)
+                    {
+                        NBX_LJ_PARAMS(i)
+                        bool any = true;
+                        pair_v2<EL, ENER, PRUNE, false>(a, xi[i], cur.xj[jm], c, 1u, true,
+                                                        fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
+                        if (PRUNE && !any) { imask &= ~bit; }
+                    }
+                }
+            }
+#undef NBX_LJ_PARAMS
+            fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
+            const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
+            if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
+            if (lane == 0) { s_fjc[nfj] = cj; }
+            nfj++;
+        }
+
+        if (PRUNE)
+        {
+            if (lane == 0)
+            {
+                a.cj4[j4].imei[0].imask = imask;
+                a.cj4[j4].imei[1].imask = imask;
+            }
+        }
+        cur = nxt;
+        if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
+    }
+    if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
+
+    float rx, ry, rz;
+    {
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        float      gx[4], gy[4], gz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            gx[k] = (h5 ? fix[k + 4] : fix[k]) + __shfl_xor(h5 ? fix[k] : fix[k + 4], 32);
+            gy[k] = (h5 ? fiy[k + 4] : fiy[k]) + __shfl_xor(h5 ? fiy[k] : fiy[k + 4], 32);
+            gz[k] = (h5 ? fiz[k + 4] : fiz[k]) + __shfl_xor(h5 ? fiz[k] : fiz[k + 4], 32);
+        }
+        float hx[2], hy[2], hz[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            hx[k] = (h4 ? gx[k + 2] : gx[k]) + __shfl_xor(h4 ? gx[k] : gx[k + 2], 16);
+            hy[k] = (h4 ? gy[k + 2] : gy[k]) + __shfl_xor(h4 ? gy[k] : gy[k + 2], 16);
+            hz[k] = (h4 ? gz[k + 2] : gz[k]) + __shfl_xor(h4 ? gz[k] : gz[k + 2], 16);
+        }
+        rx = (h3 ? hx[1] : hx[0]) + __shfl_xor(h3 ? hx[0] : hx[1], 8);
+        ry = (h3 ? hy[1] : hy[0]) + __shfl_xor(h3 ? hy[0] : hy[1], 8);
+        rz = (h3 ? hz[1] : hz[0]) + __shfl_xor(h3 ? hz[0] : hz[1], 8);
+    }
+    s_red[lane * 3 + 0] = rx;
+    s_red[lane * 3 + 1] = ry;
+    s_red[lane * 3 + 2] = rz;
+    __syncthreads();
+    {
+        float *fi = a.f + (size_t)sci * 192;
+        atomicAdd(&fi[lane], s_red[lane]);
+        atomicAdd(&fi[lane + 64], s_red[lane + 64]);
+        atomicAdd(&fi[lane + 128], s_red[lane + 128]);
+    }
+
+    if (ENER)
+    {
+        const float sx = central ? 0.0f : wave_sum(rx);
+        const float sy = central ? 0.0f : wave_sum(ry);
+        const float sz = central ? 0.0f : wave_sum(rz);
+        E_lj = wave_sum(E_lj);
+        E_el = wave_sum(E_el);
+        if (lane == 0)
+        {
+            float *p = a.partial + (size_t)blockIdx.x * NBX_PARTIAL_STRIDE;
+            p[0] = sx; p[1] = sy; p[2] = sz; p[3] = E_lj; p[4] = E_el;
+            reinterpret_cast<int *>(p)[5] = e.shift;
+        }
+    }
+#ifdef NBX_STAMPS
+    if (!ENER && lane == 0)
+    {
+        // diagnostic build only: wave lifetime and placement, into the (otherwise unused) partial record
+        unsigned long long *p = reinterpret_cast<unsigned long long *>(a.partial + (size_t)blockIdx.x * NBX_PARTIAL_STRIDE);
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p[0] = stamp0;
+        p[1] = __builtin_amdgcn_s_memrealtime();
+        p[2] = ((unsigned long long)xcc << 32) | hwid;
+        p[3] = (unsigned long long)(e.cj4_ind_end - e.cj4_ind_start);
+    }
+#endif
+}
+
 // Folds the per-entry partials into fshift[45][3], e_lj, e_el (ADDS to them, so that local
 // and non-local launches accumulate like the reference's atomics do).  One block.
 __global__ void __launch_bounds__(256) nbnxn_reduce_outputs(const float *partial, int nsci,
@@ -312,29 +638,31 @@ __global__ void __launch_bounds__(256) nbnxn_reduce_outputs(const float *partial
 }
 
 template <int EL, bool ENER, bool PRUNE>
-void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
+void launch_flavour(const nbx_kernel_args_t &a, int nsci, int variant, hipStream_t stream)
 {
-    if (a.ntype <= MAX_LDS_TYPES)
+    if (variant == 1)
     {
-        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, a);
+        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, a); }
+        else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, a); }
     }
     else
     {
-        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, a);
+        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, a); }
+        else { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, a); }
     }
 }
 
 } // namespace
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
-                                hipStream_t stream)
+                                int variant, hipStream_t stream)
 {
     if (nsci <= 0) { return hipSuccess; }
 #define NBX_DISPATCH(EL)                                                                     \
-    if (ener) { if (prune) { launch_flavour<EL, true, true>(a, nsci, stream); }              \
-                else       { launch_flavour<EL, true, false>(a, nsci, stream); } }           \
-    else      { if (prune) { launch_flavour<EL, false, true>(a, nsci, stream); }             \
-                else       { launch_flavour<EL, false, false>(a, nsci, stream); } }
+    if (ener) { if (prune) { launch_flavour<EL, true, true>(a, nsci, variant, stream); }              \
+                else       { launch_flavour<EL, true, false>(a, nsci, variant, stream); } }           \
+    else      { if (prune) { launch_flavour<EL, false, true>(a, nsci, variant, stream); }             \
+                else       { launch_flavour<EL, false, false>(a, nsci, variant, stream); } }
     if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF) }
     else { NBX_DISPATCH(NBX_EL_EWALD_ANA) }
 #undef NBX_DISPATCH

@@ -23,7 +23,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(abi.lib_dir(), "libnbnxn_hip.so")
+    path = os.environ.get("NBNXN_HIP_LIB") or os.path.join(abi.lib_dir(), "libnbnxn_hip.so")   # override: kernel A/B builds
     if not os.path.exists(path):
         raise HipError(f"{path} is missing: the HIP extension was not built (python -c 'import __graft_entry__ as g; g.build()')")
     lib = C.CDLL(path)
@@ -169,6 +169,9 @@ class NbnxnHip:
 
     def reset_timings(self):
         self._chk(self.lib.nbnxn_hip_reset_timings(self.h))
+
+    def set_kernel_variant(self, v):
+        self._chk(self.lib.nbnxn_hip_set_kernel_variant(self.h, v))
 
     def set_prune(self, iloc, on):
         self._chk(self.lib.nbnxn_hip_set_prune(self.h, iloc, int(on)))
