@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--tiles", default="5,5,6")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="do not split list entries for load balance")
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant for A/B runs (-1: library default)")
+    ap.add_argument("--mcb", type=int, default=-1, help="list split target (-1: nbnxn_hip_min_ci_balanced)")
     args = ap.parse_args()
 
     import torch
@@ -101,7 +103,10 @@ def main():
     if world == 1:
         system = g.system.water_box(*tiles, model=model)
         nb = g.gpu.NbnxnHip(local_rank)
-        prep = g.workload.prepare(system, ip, 0 if args.no_split else nb.min_ci_balanced())
+        if args.variant >= 0:
+            nb.set_kernel_variant(args.variant)
+        mcb = 0 if args.no_split else (args.mcb if args.mcb >= 0 else nb.min_ci_balanced())
+        prep = g.workload.prepare(system, ip, mcb)
         g.workload.upload(nb, prep, ip)
         assert nb.verify_pairlist(prep.pl) == 0
         natoms = system.natoms

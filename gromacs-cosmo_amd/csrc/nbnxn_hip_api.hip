@@ -103,8 +103,7 @@ struct nbnxn_hip {
     DevBuf<float>  f;
     DevBuf<int>    type;
     float         *shift_vec = nullptr;   // 45*3
-    float         *fshift = nullptr;      // 45*3
-    float         *e_lj = nullptr, *e_el = nullptr;
+    float         *out = nullptr;         // [NBX_OUT_SLOTS][NBX_OUT_STRIDE]: {e_lj, e_el, fshift[45][3]} per slot
     int            natoms = 0, natoms_local = 0, ntype = 0;
     bool           shift_vec_uploaded = false;
 
@@ -118,7 +117,7 @@ struct nbnxn_hip {
     PList plist[2];
 
     // pinned staging for the small outputs (nb_staging, nbnxn_cuda_types.h:104-110)
-    float *h_stage = nullptr;   // [0] e_lj, [1] e_el, [2..136] fshift
+    float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
 
     nbx_wallclock_gpu_t timings;
     int                 variant = 0;
@@ -182,10 +181,19 @@ int upload_nbfp(nbnxn_hip *nb, int ntype, const float *nbfp)
 
 int clear_e_fshift(nbnxn_hip *nb)
 {
-    HIP_TRY(hipMemsetAsync(nb->fshift, 0, NBX_SHIFTS * 3 * sizeof(float), nb->stream[0]));
-    HIP_TRY(hipMemsetAsync(nb->e_lj, 0, sizeof(float), nb->stream[0]));
-    HIP_TRY(hipMemsetAsync(nb->e_el, 0, sizeof(float), nb->stream[0]));
+    HIP_TRY(hipMemsetAsync(nb->out, 0, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), nb->stream[0]));
     return 0;
+}
+
+// sums the accumulation slots in double: e[0] = e_lj, e[1] = e_el, e[2..136] = fshift
+void fold_outputs(const nbnxn_hip *nb, double *e)
+{
+    for (int k = 0; k < 2 + NBX_SHIFTS * 3; k++) { e[k] = 0; }
+    for (int s = 0; s < NBX_OUT_SLOTS; s++)
+    {
+        const float *p = nb->h_stage + (size_t)s * NBX_OUT_STRIDE;
+        for (int k = 0; k < 2 + NBX_SHIFTS * 3; k++) { e[k] += p[k]; }
+    }
 }
 
 float elapsed(hipEvent_t a, hipEvent_t b)
@@ -234,7 +242,7 @@ int init_pairlist_impl(nbnxn_hip *nb, int iloc, float rlist, int nsci, const nbx
     PList      &pl = nb->plist[iloc];
     hipStream_t st = nb->stream[iloc];
     if (dev_reserve(pl.sci, nsci) || dev_reserve(pl.cj4, ncj4) || dev_reserve(pl.excl, nexcl) ||
-        dev_reserve(pl.partial, (size_t)nsci * NBX_PARTIAL_STRIDE))
+        dev_reserve(pl.partial, (size_t)nsci * (NBX_PARTIAL_STRIDE + 2)))
     {
         return 1;
     }
@@ -326,14 +334,10 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     a.two_k_rf = 2 * nb->k_rf; a.c_rf = nb->c_rf;
     a.beta = nb->beta; a.beta2 = nb->beta * nb->beta; a.beta3 = nb->beta * nb->beta * nb->beta;
     a.sh_ewald = nb->sh_ewald; a.disp_cpot = nb->disp_cpot; a.rep_cpot = nb->rep_cpot;
-    a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.partial = pl.partial.p;
+    a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.partial = pl.partial.p; a.out = nb->out;
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
     HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->variant, st));
-    if (ener)
-    {
-        HIP_TRY(nbx_launch_reduce_outputs(pl.partial.p, pl.nsci, nb->fshift, nb->e_lj, nb->e_el, st));
-    }
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
     nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
     return 0;
@@ -359,9 +363,7 @@ int cpyback_impl(nbnxn_hip *nb, float *h_f, int flags, int aloc)
     if (iloc == NBX_NONLOCAL) { HIP_TRY(hipEventRecord(nb->nonlocal_done, st)); }
     if (iloc == NBX_LOCAL && ener)
     {
-        HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->e_lj, sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(nb->h_stage + 1, nb->e_el, sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(nb->h_stage + 2, nb->fshift, NBX_SHIFTS * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->out, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
     }
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->d2h_stop[iloc], st)); nb->d2h_timed[iloc] = true; }
     return 0;
@@ -387,11 +389,13 @@ int wait_impl(nbnxn_hip *nb, int flags, int aloc, float *e_lj, float *e_el, floa
     // add up energies and shift forces, once, at the local wait (nbnxn_cuda.cu:662-680)
     if (iloc == NBX_LOCAL && ener)
     {
-        if (e_lj) { *e_lj += nb->h_stage[0]; }
-        if (e_el) { *e_el += nb->h_stage[1]; }
+        double e[2 + NBX_SHIFTS * 3];
+        fold_outputs(nb, e);
+        if (e_lj) { *e_lj += (float)e[0]; }
+        if (e_el) { *e_el += (float)e[1]; }
         if (fshift)
         {
-            for (int i = 0; i < NBX_SHIFTS * 3; i++) { fshift[i] += nb->h_stage[2 + i]; }
+            for (int i = 0; i < NBX_SHIFTS * 3; i++) { fshift[i] += (float)e[2 + i]; }
         }
     }
     pl.do_prune = false;
@@ -501,10 +505,8 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
         HIP_TRY(hipEventCreate(&nb->d2h_start[l])); HIP_TRY(hipEventCreate(&nb->d2h_stop[l]));
     }
     HIP_TRY(hipMalloc((void **)&nb->shift_vec, NBX_SHIFTS * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&nb->fshift, NBX_SHIFTS * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&nb->e_lj, sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&nb->e_el, sizeof(float)));
-    HIP_TRY(hipHostMalloc((void **)&nb->h_stage, (2 + NBX_SHIFTS * 3) * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&nb->out, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float)));
+    HIP_TRY(hipHostMalloc((void **)&nb->h_stage, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
     memset(&nb->timings, 0, sizeof(nb->timings));
     if (clear_e_fshift(nb)) { return 1; }
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
@@ -638,7 +640,7 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
         (void)hipEventDestroy(nb->h2d_start[l]); (void)hipEventDestroy(nb->h2d_stop[l]);
         (void)hipEventDestroy(nb->d2h_start[l]); (void)hipEventDestroy(nb->d2h_stop[l]);
     }
-    (void)hipFree(nb->shift_vec); (void)hipFree(nb->fshift); (void)hipFree(nb->e_lj); (void)hipFree(nb->e_el);
+    (void)hipFree(nb->shift_vec); (void)hipFree(nb->out);
     (void)hipHostFree(nb->h_stage);
     if (nb->two_streams)
     {
@@ -746,13 +748,16 @@ int nbnxn_hip_read_outputs(nbnxn_hip_ptr_t nb, float *e_lj, float *e_el, float *
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = nb->stream[0];
     if (nb->two_streams) { HIP_TRY(hipStreamSynchronize(nb->stream[1])); }
-    HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->e_lj, sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(nb->h_stage + 1, nb->e_el, sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(nb->h_stage + 2, nb->fshift, NBX_SHIFTS * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->out, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (e_lj) { *e_lj = nb->h_stage[0]; }
-    if (e_el) { *e_el = nb->h_stage[1]; }
-    if (fshift) { memcpy(fshift, nb->h_stage + 2, NBX_SHIFTS * 3 * sizeof(float)); }
+    double e[2 + NBX_SHIFTS * 3];
+    fold_outputs(nb, e);
+    if (e_lj) { *e_lj = (float)e[0]; }
+    if (e_el) { *e_el = (float)e[1]; }
+    if (fshift)
+    {
+        for (int i = 0; i < NBX_SHIFTS * 3; i++) { fshift[i] = (float)e[2 + i]; }
+    }
     return 0;
 }
 

@@ -10,8 +10,11 @@
 // LJ tables up to this many atom types are staged in LDS (2 KB); larger ones are read
 // through L1/L2.
 #define NBX_KERNEL_MAX_LDS_TYPES 16
-// floats per per-entry partial record: fshift xyz, e_lj, e_el, shift index, 2 pad
+// floats per per-entry debug record (diagnostic NBX_STAMPS build only)
 #define NBX_PARTIAL_STRIDE 8
+// energy / shift-force accumulation slots: each is {e_lj, e_el, fshift[45][3]} padded to 144 floats
+#define NBX_OUT_SLOTS 64
+#define NBX_OUT_STRIDE 144
 
 // Everything a launch needs, passed by value as the kernel argument (the reference passes
 // cu_atomdata_t / cu_nbparam_t / cu_plist_t by value: nbnxn_cuda.cu:384).
@@ -33,14 +36,13 @@ struct nbx_kernel_args_t {
     const nbx_sci_t  *sci;
     nbx_cj4_t        *cj4;
     const nbx_excl_t *excl;
-    // per-entry partial outputs [nsci][NBX_PARTIAL_STRIDE]
+    // per-entry debug records [nsci][NBX_PARTIAL_STRIDE] (diagnostic build)
     float *partial;
+    // accumulation slots [NBX_OUT_SLOTS][NBX_OUT_STRIDE]
+    float *out;
 };
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
                                 int variant, hipStream_t stream);
-
-hipError_t nbx_launch_reduce_outputs(const float *partial, int nsci, float *fshift, float *e_lj, float *e_el,
-                                     hipStream_t stream);
 
 #endif

@@ -12,13 +12,56 @@
 //   * i-forces: 24 register accumulators per lane, reduce-scattered over the 8 j-lanes at
 //     the end (21 cross-lane moves), transposed through LDS and written with three
 //     256-byte contiguous atomic instructions;
-//   * energies / shift forces: per-entry partial sums stored to HBM and folded in double
-//     precision by nbnxn_reduce_outputs (no same-address fp32 atomic chain).
+//   * energies / shift forces: wave-reduced, then added into one of NBX_OUT_SLOTS
+//     accumulation slots (slot = entry index mod slots), so no long same-address fp32 atomic
+//     chain builds up; the host folds the slots in double precision after the copy-back.
 #include <hip/hip_runtime.h>
 
 #include "nbnxn_kernel.h"
 
 namespace {
+
+
+// The list, coordinate and parameter arrays are passed as separate __restrict__ kernel
+// arguments: that gives them noalias, so the force atomics do not "clobber" them in the
+// compiler's eyes and the wave-uniform list words (sci, cj4, excl_ind) stay on the scalar
+// load path (s_load) inside the loops instead of vector loads + v_readfirstlane with a
+// full vmcnt(0) round trip each.
+#define NBX_KERNEL_PARAMS                                                                          \
+    const float4 *__restrict__ p_xq, float *__restrict__ p_f, const int *__restrict__ p_type,      \
+        const float *__restrict__ p_shift_vec, const float2 *__restrict__ p_nbfp,                   \
+        const nbx_sci_t *__restrict__ p_sci, nbx_cj4_t *__restrict__ p_cj4,                         \
+        const nbx_excl_t *__restrict__ p_excl, float *__restrict__ p_partial, float *__restrict__ p_out,   \
+        const nbx_kernel_scalars_t sc
+#define NBX_KERNEL_ARGS_FROM_PARAMS                                                                \
+    const nbx_kernel_view_t a = {p_xq, p_f, p_type, p_shift_vec, sc.ntype, p_nbfp, sc.epsfac, sc.inv_epsfac, sc.rc2, \
+                                 sc.rlist2, sc.two_k_rf, sc.c_rf, sc.beta, sc.beta2, sc.beta3, sc.sh_ewald,  \
+                                 sc.disp_cpot, sc.rep_cpot, p_sci, p_cj4, p_excl, p_partial, p_out};
+#define NBX_KERNEL_CALL_ARGS(A)                                                                    \
+    (A).xq, (A).f, (A).type, (A).shift_vec, (A).nbfp, (A).sci, (A).cj4, (A).excl, (A).partial, (A).out, \
+        nbx_kernel_scalars_t{(A).ntype, (A).epsfac, (A).inv_epsfac, (A).rc2, (A).rlist2, (A).two_k_rf, (A).c_rf, \
+                             (A).beta, (A).beta2, (A).beta3, (A).sh_ewald, (A).disp_cpot, (A).rep_cpot}
+
+struct nbx_kernel_scalars_t {
+    int   ntype;
+    float epsfac, inv_epsfac, rc2, rlist2, two_k_rf, c_rf, beta, beta2, beta3, sh_ewald, disp_cpot, rep_cpot;
+};
+
+// device-side view with the same member names as nbx_kernel_args_t
+struct nbx_kernel_view_t {
+    const float4 *__restrict__ xq;
+    float *__restrict__        f;
+    const int *__restrict__    type;
+    const float *__restrict__  shift_vec;
+    int                        ntype;
+    const float2 *__restrict__ nbfp;
+    float                      epsfac, inv_epsfac, rc2, rlist2, two_k_rf, c_rf, beta, beta2, beta3, sh_ewald, disp_cpot, rep_cpot;
+    const nbx_sci_t *__restrict__  sci;
+    nbx_cj4_t *__restrict__        cj4;
+    const nbx_excl_t *__restrict__ excl;
+    float *__restrict__            partial;
+    float *__restrict__            out;
+};
 
 // Ewald real-space correction g(w) = -(erf(z)/z - 2/sqrt(pi) exp(-z^2))/z^2, w = z^2, as
 // P6(w)/Q4(w); coefficients derived by tools/fit_pmecorr.py (max abs error 1.6e-7 in
@@ -48,6 +91,38 @@ __device__ __forceinline__ float pme_corr_f(float w)
     q = fmaf(q, w, NBX_PMEF_Q3);
     q = fmaf(q, w, NBX_PMEF_Q2);
     q = fmaf(q, w, NBX_PMEF_Q1);
+    q = fmaf(q, w, 1.0f);
+    return p * __builtin_amdgcn_rcpf(q);
+}
+
+// v(w) = erf(z)/z, w = z^2, as P5(w)/Q5(w) (tools/fit_pmecorr.py; 2.1e-7 abs error in float
+// on 0 <= w <= 16): the real-space Ewald pair energy is qq*(int_bit/r - beta*v(beta^2 r^2)),
+// which replaces the reference's 1 - erff (nbnxn_cuda_kernel.cuh:470) without exp or erf calls.
+#define NBX_PMEV_P0 1.128379158e+00f
+#define NBX_PMEV_P1 1.884112827e-01f
+#define NBX_PMEV_P2 5.244807759e-02f
+#define NBX_PMEV_P3 3.674207414e-03f
+#define NBX_PMEV_P4 2.816971822e-04f
+#define NBX_PMEV_P5 2.047197044e-06f
+#define NBX_PMEV_Q1 5.003081923e-01f
+#define NBX_PMEV_Q2 1.132520281e-01f
+#define NBX_PMEV_Q3 1.478166769e-02f
+#define NBX_PMEV_Q4 1.138623051e-03f
+#define NBX_PMEV_Q5 3.790350956e-05f
+
+__device__ __forceinline__ float pme_corr_v(float w)
+{
+    float p = NBX_PMEV_P5;
+    p = fmaf(p, w, NBX_PMEV_P4);
+    p = fmaf(p, w, NBX_PMEV_P3);
+    p = fmaf(p, w, NBX_PMEV_P2);
+    p = fmaf(p, w, NBX_PMEV_P1);
+    p = fmaf(p, w, NBX_PMEV_P0);
+    float q = NBX_PMEV_Q5;
+    q = fmaf(q, w, NBX_PMEV_Q4);
+    q = fmaf(q, w, NBX_PMEV_Q3);
+    q = fmaf(q, w, NBX_PMEV_Q2);
+    q = fmaf(q, w, NBX_PMEV_Q1);
     q = fmaf(q, w, 1.0f);
     return p * __builtin_amdgcn_rcpf(q);
 }
@@ -104,8 +179,9 @@ __device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int 
 #endif
 
 template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
+__global__ void __launch_bounds__(64) nbnxn_kernel(NBX_KERNEL_PARAMS)
 {
+    NBX_KERNEL_ARGS_FROM_PARAMS
     const int lane  = threadIdx.x;
     const int tidxi = lane & 7;
     const int tidxj = lane >> 3;
@@ -226,7 +302,7 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
                             F = fmaf(qq, fmaf(int_bit, inv_r2 * inv_r, pme_corr_f(a.beta2 * r2) * a.beta3), F);
                             if (ENER)
                             {
-                                E_el += qq * (inv_r * (int_bit - erff(r2 * inv_r * a.beta)) - int_bit * a.sh_ewald);
+                                E_el += qq * (int_bit * (inv_r - a.sh_ewald) - a.beta * pme_corr_v(a.beta2 * r2));
                             }
                         }
                         fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
@@ -301,11 +377,15 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
         const float sz = central ? 0.0f : wave_sum(rz);
         E_lj = wave_sum(E_lj);
         E_el = wave_sum(E_el);
-        if (lane == 0)
+        // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
+        float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
+        if (lane < 3)
         {
-            float *p = a.partial + (size_t)blockIdx.x * NBX_PARTIAL_STRIDE;
-            p[0] = sx; p[1] = sy; p[2] = sz; p[3] = E_lj; p[4] = E_el;
-            reinterpret_cast<int *>(p)[5] = e.shift;
+            if (!central) { atomicAdd(&slot[2 + 3 * e.shift + lane], lane == 0 ? sx : (lane == 1 ? sy : sz)); }
+        }
+        else if (lane < 5)
+        {
+            atomicAdd(&slot[lane - 3], lane == 3 ? E_lj : E_el);
         }
     }
 }
@@ -318,7 +398,7 @@ __global__ void __launch_bounds__(64) nbnxn_kernel(const nbx_kernel_args_t a)
 // arithmetic, and the four j-clusters of a cj4 group are fetched in one batch.
 // ---------------------------------------------------------------------------------------
 template <int EL, bool ENER, bool PRUNE, bool EXCL>
-__device__ __forceinline__ void pair_v2(const nbx_kernel_args_t &a, const float4 xi, const float4 xj,
+__device__ __forceinline__ void pair_v2(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
                                         const float2 c, const unsigned ebit, const bool allowed,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
                                         float &E_lj, float &E_el, bool &any_in_rlist)
@@ -354,8 +434,8 @@ __device__ __forceinline__ void pair_v2(const nbx_kernel_args_t &a, const float4
         }
         else
         {
-            const float er = erff(r2 * inv_r * a.beta);
-            eel = EXCL ? qq * (inv_r * (int_bit - er) - int_bit * a.sh_ewald) : qq * (inv_r * (1.0f - er) - a.sh_ewald);
+            const float bv = a.beta * pme_corr_v(a.beta2 * r2);
+            eel = EXCL ? qq * (int_bit * (inv_r - a.sh_ewald) - bv) : qq * (inv_r - a.sh_ewald - bv);
         }
         if (EXCL) { elj *= int_bit; }
         E_lj += cond ? elj : 0.0f;
@@ -376,7 +456,7 @@ struct nbx_jbatch_t {
     bool     has_excl;
 };
 
-__device__ __forceinline__ void load_jbatch(const nbx_kernel_args_t &a, int j4, int lane, int tidxj, nbx_jbatch_t &b)
+__device__ __forceinline__ void load_jbatch(const nbx_kernel_view_t &a, int j4, int lane, int tidxj, nbx_jbatch_t &b)
 {
     const nbx_cj4_t *g = a.cj4 + j4;
     b.imask = g->imei[0].imask | g->imei[1].imask;
@@ -395,8 +475,9 @@ __device__ __forceinline__ void load_jbatch(const nbx_kernel_args_t &a, int j4, 
 }
 
 template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_WAVES, 8))) nbnxn_kernel_v2(const nbx_kernel_args_t a)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_WAVES, 8))) nbnxn_kernel_v2(NBX_KERNEL_PARAMS)
 {
+    NBX_KERNEL_ARGS_FROM_PARAMS
     const int lane  = threadIdx.x;
     const int tidxi = lane & 7;
     const int tidxj = lane >> 3;
@@ -418,6 +499,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_
 
 #ifdef NBX_STAMPS
     const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long stampc0 = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp_wait = 0, stamp_loop0 = 0, stamp_loop1 = 0;
 #endif
     nbx_jbatch_t cur;
     if (e.cj4_ind_start < e.cj4_ind_end) { load_jbatch(a, e.cj4_ind_start, lane, tidxj, cur); }
@@ -469,6 +552,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_
 
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
     {
+#ifdef NBX_STAMPS
+        {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long tb = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp_wait += tb - ta;
+            if (stamp_loop0 == 0) { stamp_loop0 = ta; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         // software pipeline: the next group's list words and j-atoms are requested before
         // this group's arithmetic starts
         nbx_jbatch_t nxt;
@@ -537,6 +633,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_
         cur = nxt;
         if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
     }
+#ifdef NBX_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    stamp_loop1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
 
     float rx, ry, rz;
@@ -580,11 +682,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_
         const float sz = central ? 0.0f : wave_sum(rz);
         E_lj = wave_sum(E_lj);
         E_el = wave_sum(E_el);
-        if (lane == 0)
+        // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
+        float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
+        if (lane < 3)
         {
-            float *p = a.partial + (size_t)blockIdx.x * NBX_PARTIAL_STRIDE;
-            p[0] = sx; p[1] = sy; p[2] = sz; p[3] = E_lj; p[4] = E_el;
-            reinterpret_cast<int *>(p)[5] = e.shift;
+            if (!central) { atomicAdd(&slot[2 + 3 * e.shift + lane], lane == 0 ? sx : (lane == 1 ? sy : sz)); }
+        }
+        else if (lane < 5)
+        {
+            atomicAdd(&slot[lane - 3], lane == 3 ? E_lj : E_el);
         }
     }
 #ifdef NBX_STAMPS
@@ -600,41 +706,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_
         p[1] = __builtin_amdgcn_s_memrealtime();
         p[2] = ((unsigned long long)xcc << 32) | hwid;
         p[3] = (unsigned long long)(e.cj4_ind_end - e.cj4_ind_start);
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        // pack cycle counts (each < 2^21 here) into the spare words: prologue, loop, waits, epilogue
+        p[3] |= ((stamp_loop0 - stampc0) & 0xfffff) << 16 | ((stamp_loop1 - stamp_loop0) & 0xffffff) << 36;
+        p[2] |= 0;
+        reinterpret_cast<unsigned *>(a.partial)[(size_t)gridDim.x * NBX_PARTIAL_STRIDE + blockIdx.x * 2 + 0] = (unsigned)stamp_wait;
+        reinterpret_cast<unsigned *>(a.partial)[(size_t)gridDim.x * NBX_PARTIAL_STRIDE + blockIdx.x * 2 + 1] = (unsigned)(tend - stamp_loop1);
     }
 #endif
-}
-
-// Folds the per-entry partials into fshift[45][3], e_lj, e_el (ADDS to them, so that local
-// and non-local launches accumulate like the reference's atomics do).  One block.
-__global__ void __launch_bounds__(256) nbnxn_reduce_outputs(const float *partial, int nsci,
-                                                            float *fshift, float *e_lj, float *e_el)
-{
-    __shared__ double acc[NBX_SHIFTS * 3 + 2];
-    for (int k = threadIdx.x; k < NBX_SHIFTS * 3 + 2; k += blockDim.x) { acc[k] = 0; }
-    __syncthreads();
-    double elj = 0, eel = 0;
-    for (int s = threadIdx.x; s < nsci; s += blockDim.x)
-    {
-        const float *p  = partial + (size_t)s * NBX_PARTIAL_STRIDE;
-        const int    sh = reinterpret_cast<const int *>(p)[5];
-        if (sh != NBX_CENTRAL)
-        {
-            atomicAdd(&acc[3 * sh + 0], (double)p[0]);
-            atomicAdd(&acc[3 * sh + 1], (double)p[1]);
-            atomicAdd(&acc[3 * sh + 2], (double)p[2]);
-        }
-        elj += p[3];
-        eel += p[4];
-    }
-    atomicAdd(&acc[NBX_SHIFTS * 3], elj);
-    atomicAdd(&acc[NBX_SHIFTS * 3 + 1], eel);
-    __syncthreads();
-    for (int k = threadIdx.x; k < NBX_SHIFTS * 3; k += blockDim.x) { fshift[k] += (float)acc[k]; }
-    if (threadIdx.x == 0)
-    {
-        *e_lj += (float)acc[NBX_SHIFTS * 3];
-        *e_el += (float)acc[NBX_SHIFTS * 3 + 1];
-    }
 }
 
 template <int EL, bool ENER, bool PRUNE>
@@ -642,13 +721,13 @@ void launch_flavour(const nbx_kernel_args_t &a, int nsci, int variant, hipStream
 {
     if (variant == 1)
     {
-        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, a); }
-        else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, a); }
+        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+        else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
     }
     else
     {
-        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, a); }
-        else { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, a); }
+        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+        else { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
     }
 }
 
@@ -666,13 +745,5 @@ hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_typ
     if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF) }
     else { NBX_DISPATCH(NBX_EL_EWALD_ANA) }
 #undef NBX_DISPATCH
-    return hipGetLastError();
-}
-
-hipError_t nbx_launch_reduce_outputs(const float *partial, int nsci, float *fshift, float *e_lj, float *e_el,
-                                     hipStream_t stream)
-{
-    if (nsci <= 0) { return hipSuccess; }
-    hipLaunchKernelGGL(nbnxn_reduce_outputs, dim3(1), dim3(256), 0, stream, partial, nsci, fshift, e_lj, e_el);
     return hipGetLastError();
 }

@@ -31,11 +31,21 @@ def g(w):
     return out
 
 
-def fit(np_, nq_, n=4000):
+def v(w):
+    """erf(z)/z, w = z^2: the Ewald real-space potential correction (energy kernels)."""
+    w = np.asarray(w, dtype=np.float64)
+    z = np.sqrt(np.maximum(w, 1e-300))
+    out = erf(z) / z
+    out[w < 1e-12] = 2 / np.sqrt(np.pi)
+    return out
+
+
+def fit(np_, nq_, n=4000, func=None):
+    func = func or g
     # Chebyshev-distributed sample points
     t = np.cos(np.pi * (np.arange(n) + 0.5) / n)
     w = 0.5 * WMAX * (t + 1)
-    y = g(w)
+    y = func(w)
     u = w / WMAX   # scaled variable for conditioning
     wt = np.ones_like(w)
     for it in range(30):
@@ -72,3 +82,12 @@ if __name__ == "__main__":
         print("#define NBX_PMEF_P%d %.9ef" % (k, c))
     for k, c in enumerate(q):
         print("#define NBX_PMEF_Q%d %.9ef" % (k, c))
+    p, q = fit(5, 5, func=v)
+    err64 = np.abs(sum(p[k] * w ** k for k in range(6)) / sum(q[k] * w ** k for k in range(6)) - v(w))
+    err32 = np.abs(evalf32(p, q, w).astype(np.float64) - v(w))
+    print("// erf(z)/z: max abs error double %.3e, float32 evaluation %.3e (v(0) = 1.1284)" % (err64.max(), err32.max()))
+    print("// min Q on range: %.3e" % min(sum(q[k] * w ** k for k in range(6))))
+    for k, c in enumerate(p):
+        print("#define NBX_PMEV_P%d %.9ef" % (k, c))
+    for k, c in enumerate(q):
+        print("#define NBX_PMEV_Q%d %.9ef" % (k, c))

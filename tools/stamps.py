@@ -12,9 +12,22 @@ g.workload.upload(nb, p, ip)
 nb.compute(p.xq, 0)
 for rep in range(3):
     nb.clear_outputs(0); nb.launch_kernel_resident(0); nb.wait_gpu(0)
-buf = np.zeros((p.pl.nsci, 4), dtype=np.uint64)
+n = p.pl.nsci
+raw = np.zeros(n * 10, dtype=np.uint32)
 nb.lib.nbnxn_hip_debug_read_partial.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
-assert nb.lib.nbnxn_hip_debug_read_partial(nb.h, 0, abi.ptr(buf), buf.nbytes) == 0
+assert nb.lib.nbnxn_hip_debug_read_partial(nb.h, 0, abi.ptr(raw), raw.nbytes) == 0
+buf = raw[:n * 8].view(np.uint64).reshape(n, 4).copy()
+extra = raw[n * 8:].reshape(n, 2)
+w3 = buf[:, 3].copy()
+buf[:, 3] = w3 & 0xffff
+pro = ((w3 >> 16) & 0xfffff).astype(np.int64); loop = ((w3 >> 36) & 0xffffff).astype(np.int64)
+wait = extra[:, 0].astype(np.int64); epi = extra[:, 1].astype(np.int64)
+print("cycles per wave (s_memtime): prologue mean %.0f, loop mean %.0f of which exposed memory wait %.0f, epilogue %.0f" % (pro.mean(), loop.mean(), wait.mean(), epi.mean()))
+nc = (w3 & 0xffff).astype(int)
+for k in sorted(set(nc)):
+    m = nc == k
+    if m.sum() > 100:
+        print(f"   ncj4 {k}: prologue {pro[m].mean():.0f} loop {loop[m].mean():.0f} wait {wait[m].mean():.0f} epilogue {epi[m].mean():.0f}")
 t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 1].astype(np.int64)
 base = t0.min()
 t0 = (t0 - base) * 0.01; t1 = (t1 - base) * 0.01   # us (100 MHz)
