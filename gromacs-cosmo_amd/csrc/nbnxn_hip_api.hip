@@ -120,7 +120,7 @@ struct nbnxn_hip {
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
 
     nbx_wallclock_gpu_t timings;
-    int                 variant = 0;
+    int                 variant = 2;
 };
 
 namespace {

@@ -127,6 +127,54 @@ __device__ __forceinline__ float pme_corr_v(float w)
     return p * __builtin_amdgcn_rcpf(q);
 }
 
+// Force and potential corrections over ONE denominator (tools/fit_pmecorr.py jointfit: P6/Q5
+// and P5/Q5, float evaluation errors 1.7e-7 / 2.3e-7 absolute on 0 <= w <= 16): the energy
+// kernels need both, and the reciprocal is a quarter-rate instruction.
+#define NBX_PMEJ_F0 -7.522528659e-01f
+#define NBX_PMEJ_F1 7.207905358e-02f
+#define NBX_PMEJ_F2 -1.981625525e-02f
+#define NBX_PMEJ_F3 1.028096825e-03f
+#define NBX_PMEJ_F4 -6.587890910e-05f
+#define NBX_PMEJ_F5 1.812734519e-06f
+#define NBX_PMEJ_F6 -2.231291589e-08f
+#define NBX_PMEJ_V0 1.128379098e+00f
+#define NBX_PMEJ_V1 1.927866508e-01f
+#define NBX_PMEJ_V2 5.246387815e-02f
+#define NBX_PMEJ_V3 3.745746373e-03f
+#define NBX_PMEJ_V4 2.629633691e-04f
+#define NBX_PMEJ_V5 1.725974995e-06f
+#define NBX_PMEJ_Q1 5.041848465e-01f
+#define NBX_PMEJ_Q2 1.145604868e-01f
+#define NBX_PMEJ_Q3 1.489169305e-02f
+#define NBX_PMEJ_Q4 1.120914681e-03f
+#define NBX_PMEJ_Q5 3.363388774e-05f
+
+__device__ __forceinline__ void pme_corr_fv(const float w, float &gf, float &gv)
+{
+    float q = NBX_PMEJ_Q5;
+    q = fmaf(q, w, NBX_PMEJ_Q4);
+    q = fmaf(q, w, NBX_PMEJ_Q3);
+    q = fmaf(q, w, NBX_PMEJ_Q2);
+    q = fmaf(q, w, NBX_PMEJ_Q1);
+    q = fmaf(q, w, 1.0f);
+    float pf = NBX_PMEJ_F6;
+    pf = fmaf(pf, w, NBX_PMEJ_F5);
+    pf = fmaf(pf, w, NBX_PMEJ_F4);
+    pf = fmaf(pf, w, NBX_PMEJ_F3);
+    pf = fmaf(pf, w, NBX_PMEJ_F2);
+    pf = fmaf(pf, w, NBX_PMEJ_F1);
+    pf = fmaf(pf, w, NBX_PMEJ_F0);
+    float pv = NBX_PMEJ_V5;
+    pv = fmaf(pv, w, NBX_PMEJ_V4);
+    pv = fmaf(pv, w, NBX_PMEJ_V3);
+    pv = fmaf(pv, w, NBX_PMEJ_V2);
+    pv = fmaf(pv, w, NBX_PMEJ_V1);
+    pv = fmaf(pv, w, NBX_PMEJ_V0);
+    const float rq = __builtin_amdgcn_rcpf(q);
+    gf = pf * rq;
+    gv = pv * rq;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
@@ -716,10 +764,334 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 2 (nbnxn_kernel_v3).  As nbnxn_kernel_v2, with three changes that came out of reading
+// the gfx950 code of that kernel:
+//  * ONE pair body for groups with and without exclusion words.  An if/else over two bodies
+//    merges the 24 i-force accumulators at its end; the register allocator then keeps two
+//    copies of them (24 more live registers, three moves per skipped pair, 24 per skipped
+//    j-cluster).  The single body pays two instructions per pair for exclusions instead: the
+//    pair's exclusion bit is sign-extended to a 0 / ~0 word and ANDed onto the terms that
+//    vanish for excluded pairs.  r = 0 only occurs for the self pair, whose result the
+//    cut-off select discards, so no r^2 increment is needed (fillers sit at distinct
+//    positions, nbnxn_atomdata.c:288-295).
+//  * the software pipeline works per j-cluster (two rolling j-atom register sets instead of
+//    two four-cluster batches);
+//  * the eight LJ parameter pairs of a j-cluster are fetched from LDS before its first pair
+//    instead of one dependent LDS read per pair.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float and_mask(const float v, const int m)
+{
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
+}
+
+template <int EL, bool ENER, bool PRUNE>
+__device__ __forceinline__ void pair_v3(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
+                                        const float2 c, const unsigned wexcl, const int bitpos, const bool allowed,
+                                        float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
+                                        float &E_lj, float &E_el, bool &any_in_rlist)
+{
+    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (PRUNE) { any_in_rlist = __any(r2 < a.rlist2); }
+    const bool  cond = (r2 < a.rc2) && allowed;
+    // 0 for an excluded pair, all ones otherwise
+    const int   m      = __builtin_amdgcn_sbfe((int)wexcl, bitpos, 1);
+    const float inv_r  = __builtin_amdgcn_rsqf(r2);
+    const float inv_r2 = inv_r * inv_r;
+    const float inv_r6 = inv_r2 * inv_r2 * inv_r2;
+    // (F_lj + F_coulomb) * r^2, as r^-6 (c12 r^-6 - c6) + qq / r
+    const float lj6 = inv_r6 * fmaf(c.y, inv_r6, -c.x);
+    const float qq  = xi.w * xj.w;
+    // LJ + plain Coulomb vanish for excluded pairs; the reaction-field / Ewald correction stays
+    const float t = and_mask(fmaf(qq, inv_r, lj6) * inv_r2, m);
+    float       F, gv = 0.0f;
+    if (EL == NBX_EL_RF) { F = fmaf(qq, -a.two_k_rf, t); }
+    else
+    {
+        float gf;
+        if (ENER) { pme_corr_fv(a.beta2 * r2, gf, gv); }
+        else { gf = pme_corr_f(a.beta2 * r2); }
+        F = fmaf(qq, gf * a.beta3, t);
+    }
+    F = cond ? F : 0.0f;
+    if (ENER)
+    {
+        // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6 = c12 r^-12 - c6 r^-6
+        const float shift = fmaf(c.y, a.rep_cpot * (1.0f / 12.0f), c.x * (a.disp_cpot * (-1.0f / 6.0f)));
+        const float elj   = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
+        float       eel;
+        if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.two_k_rf, r2, -a.c_rf)); }
+        else { eel = qq * fmaf(-a.beta, gv, and_mask(inv_r - a.sh_ewald, m)); }
+        E_lj += cond ? elj : 0.0f;
+        E_el += cond ? eel : 0.0f;
+    }
+    fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
+    fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
+}
+
+struct nbx_jhdr_t {
+    unsigned imask;
+    int      cj[4];
+    unsigned wexcl;   // per lane
+};
+
+struct nbx_jslot_t {
+    float4 x;
+    int    t;
+};
+
+__device__ __forceinline__ void load_jhdr(const nbx_kernel_view_t &a, int j4, int lane, nbx_jhdr_t &h)
+{
+    const nbx_cj4_t *g = a.cj4 + j4;
+    h.imask = g->imei[0].imask | g->imei[1].imask;
+    const int ei0 = g->imei[0].excl_ind, ei1 = g->imei[1].excl_ind;
+    // excl[0] is the shared all-ones entry (types/nbnxn_pairlist.h:197-199): no load for it
+    h.wexcl = 0xffffffffu;
+    if ((ei0 | ei1) != 0) { h.wexcl = a.excl[lane < 32 ? ei0 : ei1].pair[lane & 31]; }
+#pragma unroll
+    for (int jm = 0; jm < 4; jm++)
+    {
+        // slots without interaction bits hold undefined j-clusters: read cluster 0 instead
+        h.cj[jm] = (h.imask >> (8 * jm)) & 0xffu ? g->cj[jm] : 0;
+    }
+}
+
+__device__ __forceinline__ void load_jslot(const nbx_kernel_view_t &a, int cj, int tidxj, nbx_jslot_t &s)
+{
+    s.x = a.xq[cj * 8 + tidxj];
+    s.t = a.type[cj * 8 + tidxj];
+}
+
+template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS, int JM>
+__device__ __forceinline__ void jcluster_v3(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
+                                            const unsigned thi, float (&fix)[8], float (&fiy)[8], float (&fiz)[8],
+                                            const nbx_jslot_t &s, const int cj, const unsigned wexcl,
+                                            unsigned &imask, const bool central, const int sci, const int tidxi,
+                                            const int tidxj, const int lane, const float2 *s_nbfp, float *s_fj,
+                                            int *s_fjc, int &nfj, float &E_lj, float &E_el)
+{
+    if (!(imask & (0xffu << (JM * 8)))) { return; }
+    float2 c[8];
+    if (NBFP_LDS)
+    {
+        const char *row = reinterpret_cast<const char *>(s_nbfp) + s.t * (MAX_LDS_TYPES * 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
+            c[i] = *reinterpret_cast<const float2 *>(row + tb);
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
+            c[i] = a.nbfp[tb * a.ntype + s.t];
+        }
+    }
+    float fjx = 0, fjy = 0, fjz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        const unsigned bit = 1u << (JM * 8 + i);
+        if (imask & bit)
+        {
+            const bool diag = central && (cj == sci * 8 + i);
+            bool       any  = true;
+            pair_v3<EL, ENER, PRUNE>(a, xi[i], s.x, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
+                                                 fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
+            if (PRUNE && !any) { imask &= ~bit; }
+        }
+    }
+    fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
+    const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
+    if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
+    if (lane == 0) { s_fjc[nfj] = cj; }
+    nfj++;
+}
+
+#ifndef NBX_V3_WAVES
+#define NBX_V3_WAVES 4
+#endif
+
+template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_WAVES, 8))) nbnxn_kernel_v3(NBX_KERNEL_PARAMS)
+{
+    NBX_KERNEL_ARGS_FROM_PARAMS
+    const int lane  = threadIdx.x;
+    const int tidxi = lane & 7;
+    const int tidxj = lane >> 3;
+
+    __shared__ float4 s_xqi[64];
+    __shared__ int    s_ti[64];
+    __shared__ float  s_red[192];
+    // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
+    __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
+    constexpr int     FJ_CAP = 32;
+    __shared__ float  s_fj[FJ_CAP * 24];
+    __shared__ int    s_fjc[FJ_CAP];
+    int               nfj = 0;
+
+    const nbx_sci_t e     = a.sci[blockIdx.x];
+    const int       sci   = e.sci;
+    const int       ntype = a.ntype;
+    const bool      central = (e.shift == NBX_CENTRAL);
+
+    nbx_jhdr_t  cur;
+    nbx_jslot_t sa, sb;
+    cur.imask = 0; cur.wexcl = 0xffffffffu;
+    cur.cj[0] = cur.cj[1] = cur.cj[2] = cur.cj[3] = 0;
+    if (e.cj4_ind_start < e.cj4_ind_end) { load_jhdr(a, e.cj4_ind_start, lane, cur); }
+    load_jslot(a, cur.cj[0], tidxj, sa);
+
+    {
+        const int ai = sci * 64 + lane;
+        float4    x  = a.xq[ai];
+        x.x += a.shift_vec[3 * e.shift + 0];
+        x.y += a.shift_vec[3 * e.shift + 1];
+        x.z += a.shift_vec[3 * e.shift + 2];
+        x.w *= a.epsfac;
+        s_xqi[lane] = x;
+        s_ti[lane]  = a.type[ai];
+        if (NBFP_LDS)
+        {
+            for (int k = lane; k < ntype * ntype; k += 64)
+            {
+                const int t_i = k / ntype, t_j = k - t_i * ntype;
+                s_nbfp[t_j * MAX_LDS_TYPES + t_i] = a.nbfp[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
+    // their types are packed one per byte (LDS path: as byte offsets type*8 into a table row)
+    float4   xi[8];
+    unsigned tlo = 0, thi = 0;
+    float    fix[8], fiy[8], fiz[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        xi[i] = s_xqi[i * 8 + tidxi];
+        const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? 8u : 1u);
+        if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
+        fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
+    }
+
+    float E_lj = 0, E_el = 0;
+    if (ENER)
+    {
+        if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
+        {
+            const float q  = s_xqi[lane].w;
+            const float q2 = q * q * a.inv_epsfac;
+            E_el = (EL == NBX_EL_RF) ? -0.5f * a.c_rf * q2 : -a.beta * 0.564189583547756f * q2;
+        }
+    }
+
+#define NBX_V3_JCLUSTER(JM, SLOT)                                                                             \
+    jcluster_v3<EL, ENER, PRUNE, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
+                                               imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
+                                               nfj, E_lj, E_el)
+    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
+    {
+        // software pipeline: the next group's list words are requested before this group's
+        // arithmetic starts, each j-cluster's atoms one j-cluster ahead
+        nbx_jhdr_t nxt;
+        nxt.imask = 0; nxt.wexcl = 0xffffffffu;
+        nxt.cj[0] = nxt.cj[1] = nxt.cj[2] = nxt.cj[3] = 0;
+        if (j4 + 1 < e.cj4_ind_end) { load_jhdr(a, j4 + 1, lane, nxt); }
+
+        unsigned imask = cur.imask;
+        load_jslot(a, cur.cj[1], tidxj, sb);
+        NBX_V3_JCLUSTER(0, sa);
+        load_jslot(a, cur.cj[2], tidxj, sa);
+        NBX_V3_JCLUSTER(1, sb);
+        load_jslot(a, cur.cj[3], tidxj, sb);
+        NBX_V3_JCLUSTER(2, sa);
+        load_jslot(a, nxt.cj[0], tidxj, sa);
+        NBX_V3_JCLUSTER(3, sb);
+
+        if (PRUNE)
+        {
+            if (lane == 0)
+            {
+                a.cj4[j4].imei[0].imask = imask;
+                a.cj4[j4].imei[1].imask = imask;
+            }
+        }
+        cur = nxt;
+        if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
+    }
+#undef NBX_V3_JCLUSTER
+    if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
+
+    float rx, ry, rz;
+    {
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        float      gx[4], gy[4], gz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            gx[k] = (h5 ? fix[k + 4] : fix[k]) + __shfl_xor(h5 ? fix[k] : fix[k + 4], 32);
+            gy[k] = (h5 ? fiy[k + 4] : fiy[k]) + __shfl_xor(h5 ? fiy[k] : fiy[k + 4], 32);
+            gz[k] = (h5 ? fiz[k + 4] : fiz[k]) + __shfl_xor(h5 ? fiz[k] : fiz[k + 4], 32);
+        }
+        float hx[2], hy[2], hz[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            hx[k] = (h4 ? gx[k + 2] : gx[k]) + __shfl_xor(h4 ? gx[k] : gx[k + 2], 16);
+            hy[k] = (h4 ? gy[k + 2] : gy[k]) + __shfl_xor(h4 ? gy[k] : gy[k + 2], 16);
+            hz[k] = (h4 ? gz[k + 2] : gz[k]) + __shfl_xor(h4 ? gz[k] : gz[k + 2], 16);
+        }
+        rx = (h3 ? hx[1] : hx[0]) + __shfl_xor(h3 ? hx[0] : hx[1], 8);
+        ry = (h3 ? hy[1] : hy[0]) + __shfl_xor(h3 ? hy[0] : hy[1], 8);
+        rz = (h3 ? hz[1] : hz[0]) + __shfl_xor(h3 ? hz[0] : hz[1], 8);
+    }
+    s_red[lane * 3 + 0] = rx;
+    s_red[lane * 3 + 1] = ry;
+    s_red[lane * 3 + 2] = rz;
+    __syncthreads();
+    {
+        float *fi = a.f + (size_t)sci * 192;
+        atomicAdd(&fi[lane], s_red[lane]);
+        atomicAdd(&fi[lane + 64], s_red[lane + 64]);
+        atomicAdd(&fi[lane + 128], s_red[lane + 128]);
+    }
+
+    if (ENER)
+    {
+        const float sx = central ? 0.0f : wave_sum(rx);
+        const float sy = central ? 0.0f : wave_sum(ry);
+        const float sz = central ? 0.0f : wave_sum(rz);
+        E_lj = wave_sum(E_lj);
+        E_el = wave_sum(E_el);
+        // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
+        float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
+        if (lane < 3)
+        {
+            if (!central) { atomicAdd(&slot[2 + 3 * e.shift + lane], lane == 0 ? sx : (lane == 1 ? sy : sz)); }
+        }
+        else if (lane < 5)
+        {
+            atomicAdd(&slot[lane - 3], lane == 3 ? E_lj : E_el);
+        }
+    }
+}
+
 template <int EL, bool ENER, bool PRUNE>
 void launch_flavour(const nbx_kernel_args_t &a, int nsci, int variant, hipStream_t stream)
 {
-    if (variant == 1)
+    if (variant == 2)
+    {
+        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel_v3<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+        else { hipLaunchKernelGGL((nbnxn_kernel_v3<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    }
+    else if (variant == 1)
     {
         if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
         else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }

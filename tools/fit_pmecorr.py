@@ -60,6 +60,29 @@ def fit(np_, nq_, n=4000, func=None):
     return p, q
 
 
+def jointfit(npf, npv, nq, n=4000, iters=40):
+    """Force and potential corrections with ONE denominator: Pf(w)/Q(w) ~ g(w), Pv(w)/Q(w) ~ v(w),
+    so that the energy kernels need a single reciprocal per pair.  Same linearised least
+    squares + Sanathanan-Koerner reweighting as fit(), both residuals stacked."""
+    t = np.cos(np.pi * (np.arange(n) + 0.5) / n)
+    w = 0.5 * WMAX * (t + 1)
+    u = w / WMAX
+    yf, yv = g(w), v(w)
+    wt = np.ones_like(w)
+    for it in range(iters):
+        Uf = np.stack([u ** k for k in range(npf + 1)], 1)
+        Uv = np.stack([u ** k for k in range(npv + 1)], 1)
+        Uq = np.stack([u ** k for k in range(1, nq + 1)], 1)
+        A = np.concatenate([np.concatenate([Uf, np.zeros_like(Uv), -yf[:, None] * Uq], 1) * wt[:, None],
+                            np.concatenate([np.zeros_like(Uf), Uv, -yv[:, None] * Uq], 1) * wt[:, None]], 0)
+        sol, *_ = np.linalg.lstsq(A, np.concatenate([yf * wt, yv * wt]), rcond=None)
+        pf, pv = sol[:npf + 1], sol[npf + 1:npf + npv + 2]
+        q = np.concatenate([[1.0], sol[npf + npv + 2:]])
+        wt = 1 / np.abs(sum(q[k] * u ** k for k in range(nq + 1)))
+    sc = lambda c: np.array([c[k] / WMAX ** k for k in range(len(c))])
+    return sc(pf), sc(pv), sc(q)
+
+
 def evalf32(p, q, w):
     w = w.astype(np.float32)
     P = np.float32(p[-1]) * np.ones_like(w)
@@ -91,3 +114,14 @@ if __name__ == "__main__":
         print("#define NBX_PMEV_P%d %.9ef" % (k, c))
     for k, c in enumerate(q):
         print("#define NBX_PMEV_Q%d %.9ef" % (k, c))
+    pf, pv, q = jointfit(6, 5, 5)
+    ef = np.abs(evalf32(pf, q, w).astype(np.float64) - g(w)).max()
+    ev = np.abs(evalf32(pv, q, w).astype(np.float64) - v(w)).max()
+    print("// joint fit, common denominator: float32 evaluation max abs error force %.3e potential %.3e" % (ef, ev))
+    print("// min Q on range: %.3e" % min(sum(q[k] * w ** k for k in range(6))))
+    for k, c in enumerate(pf):
+        print("#define NBX_PMEJ_F%d %.9ef" % (k, c))
+    for k, c in enumerate(pv):
+        print("#define NBX_PMEJ_V%d %.9ef" % (k, c))
+    for k, c in enumerate(q):
+        print("#define NBX_PMEJ_Q%d %.9ef" % (k, c))
