@@ -19,6 +19,8 @@ FORCE_VIRIAL = 1 << 8
 FORCE_ENERGY = 1 << 9
 
 LOCAL, NONLOCAL = 0, 1
+# accumulation slots of the device output buffer (csrc/nbnxn_kernel.h)
+OUT_SLOTS, OUT_STRIDE = 64, 144
 EL_RF, EL_EWALD_ANA = 0, 1
 EEL_CUT, EEL_RF, EEL_GRF, EEL_PME, EEL_EWALD = 0, 1, 2, 3, 4
 VDW_CUT = 0

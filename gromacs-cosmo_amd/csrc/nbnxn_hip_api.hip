@@ -78,7 +78,6 @@ struct PList {
     DevBuf<nbx_sci_t>  sci;
     DevBuf<nbx_cj4_t>  cj4;
     DevBuf<nbx_excl_t> excl;
-    DevBuf<float>      partial;
     int                nsci = 0, ncj4 = 0, nexcl = 0, nci_tot = 0;
     float              rlist = 0;
     bool               do_prune = false;
@@ -117,10 +116,10 @@ struct nbnxn_hip {
     PList plist[2];
 
     // pinned staging for the small outputs (nb_staging, nbnxn_cuda_types.h:104-110)
+    float *fbase   = nullptr;   // one allocation: [out slots][f], so one memset clears both
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
 
     nbx_wallclock_gpu_t timings;
-    int                 variant = 2;
 };
 
 namespace {
@@ -176,6 +175,27 @@ int upload_nbfp(nbnxn_hip *nb, int ntype, const float *nbfp)
     HIP_TRY(hipMemcpyAsync(nb->nbfp.p, nbfp, (size_t)ntype * ntype * sizeof(float2), hipMemcpyHostToDevice, nb->stream[0]));
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
     nb->ntype = ntype;
+    return 0;
+}
+
+constexpr size_t OUT_FLOATS = (size_t)NBX_OUT_SLOTS * NBX_OUT_STRIDE;
+
+// the force array lives behind the energy / shift-force slots in one allocation
+int reserve_f(nbnxn_hip *nb, size_t n, bool *realloced)
+{
+    *realloced = false;
+    if (n > nb->f.alloc || !nb->fbase)
+    {
+        if (nb->fbase) { HIP_TRY(hipFree(nb->fbase)); nb->fbase = nullptr; }
+        const size_t na = n + n / 5 + 64;
+        HIP_TRY(hipMalloc((void **)&nb->fbase, (OUT_FLOATS + na) * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(nb->fbase, 0, OUT_FLOATS * sizeof(float), nb->stream[0]));
+        nb->out     = nb->fbase;
+        nb->f.p     = nb->fbase + OUT_FLOATS;
+        nb->f.alloc = na;
+        *realloced  = true;
+    }
+    nb->f.n = n;
     return 0;
 }
 
@@ -241,8 +261,7 @@ int init_pairlist_impl(nbnxn_hip *nb, int iloc, float rlist, int nsci, const nbx
     }
     PList      &pl = nb->plist[iloc];
     hipStream_t st = nb->stream[iloc];
-    if (dev_reserve(pl.sci, nsci) || dev_reserve(pl.cj4, ncj4) || dev_reserve(pl.excl, nexcl) ||
-        dev_reserve(pl.partial, (size_t)nsci * (NBX_PARTIAL_STRIDE + 2)))
+    if (dev_reserve(pl.sci, nsci) || dev_reserve(pl.cj4, ncj4) || dev_reserve(pl.excl, nexcl))
     {
         return 1;
     }
@@ -280,7 +299,7 @@ int init_atomdata_impl(nbnxn_hip *nb, int natoms, int natoms_local, int ntype, c
         if (type[i] < 0 || type[i] >= ntype) { return nbx_fail("atom %d has type %d outside [0,%d)", i, type[i], ntype); }
     }
     bool re = false;
-    if (dev_reserve(nb->xq, natoms) || dev_reserve(nb->type, natoms) || dev_reserve(nb->f, (size_t)natoms * 3, &re)) { return 1; }
+    if (dev_reserve(nb->xq, natoms) || dev_reserve(nb->type, natoms) || reserve_f(nb, (size_t)natoms * 3, &re)) { return 1; }
     nb->natoms = natoms; nb->natoms_local = natoms_local;
     hipStream_t st = nb->stream[0];
     if (re && natoms > 0)
@@ -329,15 +348,31 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     nbx_kernel_args_t a;
     a.xq = nb->xq.p; a.f = nb->f.p; a.type = nb->type.p; a.shift_vec = nb->shift_vec; a.ntype = nb->ntype;
     a.nbfp = nb->nbfp.p;
-    a.epsfac = nb->epsfac; a.inv_epsfac = 1.0f / nb->epsfac;
-    a.rc2 = nb->rcoulomb * nb->rcoulomb; a.rlist2 = pl.rlist * pl.rlist;
-    a.two_k_rf = 2 * nb->k_rf; a.c_rf = nb->c_rf;
-    a.beta = nb->beta; a.beta2 = nb->beta * nb->beta; a.beta3 = nb->beta * nb->beta * nb->beta;
-    a.sh_ewald = nb->sh_ewald; a.disp_cpot = nb->disp_cpot; a.rep_cpot = nb->rep_cpot;
-    a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.partial = pl.partial.p; a.out = nb->out;
+    a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.out = nb->out;
+    {
+        // kernel-ready constants (nbnxn_kernel.h: nbx_kernel_k_t), rounded once from double
+        const bool   ew = (nb->el_type != NBX_EL_RF);
+        const double b  = ew ? (double)nb->beta : 1.0;
+        a.k.xscale   = (float)b;
+        a.k.qscale   = (float)((double)nb->epsfac * b * b);
+        a.k.c6scale  = (float)std::pow(b, 7);
+        a.k.c12scale = (float)std::pow(b, 13);
+        a.k.escale   = (float)(1.0 / b);
+        a.k.rc2      = (float)(b * b * (double)nb->rcoulomb * (double)nb->rcoulomb);
+        a.k.rlist2   = (float)(b * b * (double)pl.rlist * (double)pl.rlist);
+        a.k.sh       = (float)((double)nb->sh_ewald / b);
+        a.k.rep12    = (float)((double)nb->rep_cpot / 12.0 / std::pow(b, 12));
+        a.k.ndisp6   = (float)(-(double)nb->disp_cpot / 6.0 / std::pow(b, 6));
+        // E_self = -c q_raw^2 epsfac with c = c_rf / 2 | beta / sqrt(pi); the kernel has q' = qscale q_raw
+        // and multiplies the sum by escale at the end
+        const double cself = ew ? (double)nb->beta * 0.5641895835477563 : 0.5 * (double)nb->c_rf;
+        a.k.two_k_rf = 2 * nb->k_rf;
+        a.k.c_rf     = nb->c_rf;
+        a.k.self     = (float)(-cself * (double)nb->epsfac / ((double)a.k.qscale * (double)a.k.qscale) * b);
+    }
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
-    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->variant, st));
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, st));
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
     nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
     return 0;
@@ -497,7 +532,9 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     {
         nb->stream[1] = nb->stream[0];
     }
-    nb->do_time = (getenv("GMX_DISABLE_HIP_TIMING") == nullptr);
+    // event timing is off with two streams, as in the reference (nbnxn_cuda_data_mgmt.cu:626-627):
+    // the events serialise the streams; on MI355X a pair also costs ~7 us of device time per launch
+    nb->do_time = !nb->two_streams && (getenv("GMX_DISABLE_HIP_TIMING") == nullptr);
     for (int l = 0; l < 2; l++)
     {
         HIP_TRY(hipEventCreate(&nb->k_start[l]));   HIP_TRY(hipEventCreate(&nb->k_stop[l]));
@@ -505,7 +542,7 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
         HIP_TRY(hipEventCreate(&nb->d2h_start[l])); HIP_TRY(hipEventCreate(&nb->d2h_stop[l]));
     }
     HIP_TRY(hipMalloc((void **)&nb->shift_vec, NBX_SHIFTS * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&nb->out, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float)));
+    { bool re; if (reserve_f(nb, 0, &re)) { return 1; } }
     HIP_TRY(hipHostMalloc((void **)&nb->h_stage, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
     memset(&nb->timings, 0, sizeof(nb->timings));
     if (clear_e_fshift(nb)) { return 1; }
@@ -619,11 +656,12 @@ int nbnxn_hip_clear_outputs(nbnxn_hip_ptr_t nb, int flags)
 {
     if (check_handle(nb)) { return 1; }
     HIP_TRY(hipSetDevice(nb->device));
-    if (nb->natoms > 0) { HIP_TRY(hipMemsetAsync(nb->f.p, 0, (size_t)nb->natoms * 3 * sizeof(float), nb->stream[0])); }
     if (flags & NBX_FORCE_VIRIAL)
     {
-        if (clear_e_fshift(nb)) { return 1; }
+        // slots and forces are adjacent: one fill
+        HIP_TRY(hipMemsetAsync(nb->fbase, 0, (OUT_FLOATS + (size_t)nb->natoms * 3) * sizeof(float), nb->stream[0]));
     }
+    else if (nb->natoms > 0) { HIP_TRY(hipMemsetAsync(nb->f.p, 0, (size_t)nb->natoms * 3 * sizeof(float), nb->stream[0])); }
     return 0;
 }
 
@@ -632,15 +670,15 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     if (!nb) { return 0; }
     (void)hipSetDevice(nb->device);
     (void)hipDeviceSynchronize();
-    dev_free(nb->xq); dev_free(nb->f); dev_free(nb->type); dev_free(nb->nbfp);
+    dev_free(nb->xq); (void)hipFree(nb->fbase); nb->fbase = nullptr; nb->f = DevBuf<float>(); nb->out = nullptr; dev_free(nb->type); dev_free(nb->nbfp);
     for (int l = 0; l < 2; l++)
     {
-        dev_free(nb->plist[l].sci); dev_free(nb->plist[l].cj4); dev_free(nb->plist[l].excl); dev_free(nb->plist[l].partial);
+        dev_free(nb->plist[l].sci); dev_free(nb->plist[l].cj4); dev_free(nb->plist[l].excl);
         (void)hipEventDestroy(nb->k_start[l]);   (void)hipEventDestroy(nb->k_stop[l]);
         (void)hipEventDestroy(nb->h2d_start[l]); (void)hipEventDestroy(nb->h2d_stop[l]);
         (void)hipEventDestroy(nb->d2h_start[l]); (void)hipEventDestroy(nb->d2h_stop[l]);
     }
-    (void)hipFree(nb->shift_vec); (void)hipFree(nb->out);
+    (void)hipFree(nb->shift_vec);
     (void)hipHostFree(nb->h_stage);
     if (nb->two_streams)
     {
@@ -667,12 +705,13 @@ int nbnxn_hip_reset_timings(nbnxn_hip_ptr_t nb)
 int nbnxn_hip_min_ci_balanced(nbnxn_hip_ptr_t nb)
 {
     // The reference asks for 40 entries per multiprocessor (nbnxn_cuda_data_mgmt.cu:76).
-    // One entry is one wave64 here and a CU runs up to 32 of them (8 per SIMD), so the
-    // same factor keeps every SIMD supplied with several waves over the kernel's tail.
+    // One entry is one wave64 here and a CU holds 16 of them (4 per SIMD); measured on the
+    // 97,200-atom water box, 60 per CU (15 per SIMD) is the best trade between the kernel's
+    // tail and the per-entry prologue/epilogue (40: 633, 60: 654, 80: 650 Gpair/s).
     int        ncu = 256;
     hipDeviceProp_t p;
     if (nb && hipGetDeviceProperties(&p, nb->device) == hipSuccess) { ncu = p.multiProcessorCount; }
-    return 40 * ncu;
+    return 60 * ncu;
 }
 
 int nbnxn_hip_is_kernel_ewald_analytical(const nbnxn_hip_ptr_t nb) { return nb && nb->el_type == NBX_EL_EWALD_ANA; }
@@ -733,6 +772,15 @@ int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, vo
     if (d_xq) { *d_xq = nb->xq.p; }
     if (d_f) { *d_f = nb->f.p; }
     if (d_type) { *d_type = nb->type.p; }
+    return 0;
+}
+
+int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, int *stride)
+{
+    if (check_handle(nb)) { return 1; }
+    if (d_out) { *d_out = nb->out; }
+    if (nslots) { *nslots = NBX_OUT_SLOTS; }
+    if (stride) { *stride = NBX_OUT_STRIDE; }
     return 0;
 }
 
@@ -822,16 +870,6 @@ float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc)
     return elapsed(nb->k_start[iloc], nb->k_stop[iloc]);
 }
 
-// diagnostic helper (not in the public header): raw copy of the per-entry partial records
-int nbnxn_hip_debug_read_partial(nbnxn_hip_ptr_t nb, int iloc, void *buf, size_t nbytes)
-{
-    if (check_handle(nb) || check_loc(iloc)) { return 1; }
-    HIP_TRY(hipDeviceSynchronize());
-    if (nbytes > nb->plist[iloc].partial.alloc * sizeof(float)) { return nbx_fail("partial buffer is smaller"); }
-    HIP_TRY(hipMemcpy(buf, nb->plist[iloc].partial.p, nbytes, hipMemcpyDeviceToHost));
-    return 0;
-}
-
 int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)
 {
     if (check_handle(nb) || check_loc(iloc)) { return 1; }
@@ -839,10 +877,18 @@ int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)
     return 0;
 }
 
+int nbnxn_hip_set_timing(nbnxn_hip_ptr_t nb, int on)
+{
+    if (check_handle(nb)) { return 1; }
+    nb->do_time = on != 0;
+    for (int l = 0; l < 2; l++) { nb->k_timed[l] = nb->h2d_timed[l] = nb->d2h_timed[l] = false; }
+    return 0;
+}
+
 int nbnxn_hip_set_kernel_variant(nbnxn_hip_ptr_t nb, int variant)
 {
     if (check_handle(nb)) { return 1; }
-    nb->variant = variant;
+    if (variant != 0) { return nbx_fail("kernel variant %d does not exist (this build has variant 0 only)", variant); }
     return 0;
 }
 

@@ -10,14 +10,33 @@
 // LJ tables up to this many atom types are staged in LDS (2 KB); larger ones are read
 // through L1/L2.
 #define NBX_KERNEL_MAX_LDS_TYPES 16
-// floats per per-entry debug record (diagnostic NBX_STAMPS build only)
-#define NBX_PARTIAL_STRIDE 8
 // energy / shift-force accumulation slots: each is {e_lj, e_el, fshift[45][3]} padded to 144 floats
 #define NBX_OUT_SLOTS 64
 #define NBX_OUT_STRIDE 144
 
-// Everything a launch needs, passed by value as the kernel argument (the reference passes
-// cu_atomdata_t / cu_nbparam_t / cu_plist_t by value: nbnxn_cuda.cu:384).
+// Kernel-ready constants, derived on the host in double (nbnxn_hip_api.hip: fill_kernel_consts).
+// For analytical Ewald the kernel works in coordinates scaled by beta, so that
+// r'^2 = (beta r)^2 is directly the argument of the correction fits and no pair ever
+// multiplies by beta: with u = 1/r' the pair force over r' is
+//   qq beta^2 (m u^3 + g(r'^2)) + m u^8 (c12 beta^13 u^6 - c6 beta^7)      (m: exclusion bit)
+// and the energies come out multiplied by beta.  For reaction field all scales are 1.
+struct nbx_kernel_k_t {
+    float xscale;      // beta | 1: multiplies coordinates
+    float qscale;      // epsfac beta^2 | epsfac: multiplies the i-charges
+    float c6scale;     // beta^7 | 1
+    float c12scale;    // beta^13 | 1
+    float escale;      // 1/beta | 1: multiplies the accumulated energies at the end
+    float rc2, rlist2; // scaled cut-off and list radius, squared
+    float sh;          // sh_ewald / beta
+    float rep12;       // rep_cpot / 12, scaled by beta^-12 for Ewald
+    float ndisp6;      // -disp_cpot / 6, scaled by beta^-6 for Ewald
+    float self;        // coefficient of q_i'^2 (scaled charges) in the scaled self energy
+    float two_k_rf;    // reaction field: 2 k_rf
+    float c_rf;        // reaction field: c_rf
+};
+
+// Everything a launch needs (the reference passes cu_atomdata_t / cu_nbparam_t / cu_plist_t
+// by value: nbnxn_cuda.cu:384).
 struct nbx_kernel_args_t {
     // atom data (cu_atomdata_t, nbnxn_cuda_types.h:114-139)
     const float4 *xq;
@@ -26,23 +45,17 @@ struct nbx_kernel_args_t {
     const float  *shift_vec;
     int           ntype;
     // parameters (cu_nbparam_t, :142-185)
-    const float2 *nbfp;
-    float         epsfac, inv_epsfac;
-    float         rc2, rlist2;
-    float         two_k_rf, c_rf;
-    float         beta, beta2, beta3, sh_ewald;
-    float         disp_cpot, rep_cpot;
+    const float2  *nbfp;
+    nbx_kernel_k_t k;
     // pair list (cu_plist_t, :188-204)
     const nbx_sci_t  *sci;
     nbx_cj4_t        *cj4;
     const nbx_excl_t *excl;
-    // per-entry debug records [nsci][NBX_PARTIAL_STRIDE] (diagnostic build)
-    float *partial;
     // accumulation slots [NBX_OUT_SLOTS][NBX_OUT_STRIDE]
     float *out;
 };
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
-                                int variant, hipStream_t stream);
+                                hipStream_t stream);
 
 #endif

@@ -31,21 +31,12 @@ namespace {
     const float4 *__restrict__ p_xq, float *__restrict__ p_f, const int *__restrict__ p_type,      \
         const float *__restrict__ p_shift_vec, const float2 *__restrict__ p_nbfp,                   \
         const nbx_sci_t *__restrict__ p_sci, nbx_cj4_t *__restrict__ p_cj4,                         \
-        const nbx_excl_t *__restrict__ p_excl, float *__restrict__ p_partial, float *__restrict__ p_out,   \
-        const nbx_kernel_scalars_t sc
+        const nbx_excl_t *__restrict__ p_excl, float *__restrict__ p_out, const int p_ntype,        \
+        const nbx_kernel_k_t p_k
 #define NBX_KERNEL_ARGS_FROM_PARAMS                                                                \
-    const nbx_kernel_view_t a = {p_xq, p_f, p_type, p_shift_vec, sc.ntype, p_nbfp, sc.epsfac, sc.inv_epsfac, sc.rc2, \
-                                 sc.rlist2, sc.two_k_rf, sc.c_rf, sc.beta, sc.beta2, sc.beta3, sc.sh_ewald,  \
-                                 sc.disp_cpot, sc.rep_cpot, p_sci, p_cj4, p_excl, p_partial, p_out};
+    const nbx_kernel_view_t a = {p_xq, p_f, p_type, p_shift_vec, p_ntype, p_nbfp, p_sci, p_cj4, p_excl, p_out, p_k};
 #define NBX_KERNEL_CALL_ARGS(A)                                                                    \
-    (A).xq, (A).f, (A).type, (A).shift_vec, (A).nbfp, (A).sci, (A).cj4, (A).excl, (A).partial, (A).out, \
-        nbx_kernel_scalars_t{(A).ntype, (A).epsfac, (A).inv_epsfac, (A).rc2, (A).rlist2, (A).two_k_rf, (A).c_rf, \
-                             (A).beta, (A).beta2, (A).beta3, (A).sh_ewald, (A).disp_cpot, (A).rep_cpot}
-
-struct nbx_kernel_scalars_t {
-    int   ntype;
-    float epsfac, inv_epsfac, rc2, rlist2, two_k_rf, c_rf, beta, beta2, beta3, sh_ewald, disp_cpot, rep_cpot;
-};
+    (A).xq, (A).f, (A).type, (A).shift_vec, (A).nbfp, (A).sci, (A).cj4, (A).excl, (A).out, (A).ntype, (A).k
 
 // device-side view with the same member names as nbx_kernel_args_t
 struct nbx_kernel_view_t {
@@ -55,12 +46,11 @@ struct nbx_kernel_view_t {
     const float *__restrict__  shift_vec;
     int                        ntype;
     const float2 *__restrict__ nbfp;
-    float                      epsfac, inv_epsfac, rc2, rlist2, two_k_rf, c_rf, beta, beta2, beta3, sh_ewald, disp_cpot, rep_cpot;
     const nbx_sci_t *__restrict__  sci;
     nbx_cj4_t *__restrict__        cj4;
     const nbx_excl_t *__restrict__ excl;
-    float *__restrict__            partial;
     float *__restrict__            out;
+    nbx_kernel_k_t                 k;
 };
 
 // Ewald real-space correction g(w) = -(erf(z)/z - 2/sqrt(pi) exp(-z^2))/z^2, w = z^2, as
@@ -91,38 +81,6 @@ __device__ __forceinline__ float pme_corr_f(float w)
     q = fmaf(q, w, NBX_PMEF_Q3);
     q = fmaf(q, w, NBX_PMEF_Q2);
     q = fmaf(q, w, NBX_PMEF_Q1);
-    q = fmaf(q, w, 1.0f);
-    return p * __builtin_amdgcn_rcpf(q);
-}
-
-// v(w) = erf(z)/z, w = z^2, as P5(w)/Q5(w) (tools/fit_pmecorr.py; 2.1e-7 abs error in float
-// on 0 <= w <= 16): the real-space Ewald pair energy is qq*(int_bit/r - beta*v(beta^2 r^2)),
-// which replaces the reference's 1 - erff (nbnxn_cuda_kernel.cuh:470) without exp or erf calls.
-#define NBX_PMEV_P0 1.128379158e+00f
-#define NBX_PMEV_P1 1.884112827e-01f
-#define NBX_PMEV_P2 5.244807759e-02f
-#define NBX_PMEV_P3 3.674207414e-03f
-#define NBX_PMEV_P4 2.816971822e-04f
-#define NBX_PMEV_P5 2.047197044e-06f
-#define NBX_PMEV_Q1 5.003081923e-01f
-#define NBX_PMEV_Q2 1.132520281e-01f
-#define NBX_PMEV_Q3 1.478166769e-02f
-#define NBX_PMEV_Q4 1.138623051e-03f
-#define NBX_PMEV_Q5 3.790350956e-05f
-
-__device__ __forceinline__ float pme_corr_v(float w)
-{
-    float p = NBX_PMEV_P5;
-    p = fmaf(p, w, NBX_PMEV_P4);
-    p = fmaf(p, w, NBX_PMEV_P3);
-    p = fmaf(p, w, NBX_PMEV_P2);
-    p = fmaf(p, w, NBX_PMEV_P1);
-    p = fmaf(p, w, NBX_PMEV_P0);
-    float q = NBX_PMEV_Q5;
-    q = fmaf(q, w, NBX_PMEV_Q4);
-    q = fmaf(q, w, NBX_PMEV_Q3);
-    q = fmaf(q, w, NBX_PMEV_Q2);
-    q = fmaf(q, w, NBX_PMEV_Q1);
     q = fmaf(q, w, 1.0f);
     return p * __builtin_amdgcn_rcpf(q);
 }
@@ -222,551 +180,12 @@ __device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int 
 
 
 
-#ifndef NBX_V2_WAVES
-#define NBX_V2_WAVES 3
-#endif
-
-template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) nbnxn_kernel(NBX_KERNEL_PARAMS)
-{
-    NBX_KERNEL_ARGS_FROM_PARAMS
-    const int lane  = threadIdx.x;
-    const int tidxi = lane & 7;
-    const int tidxj = lane >> 3;
-
-    __shared__ float4 s_xqi[64];
-    __shared__ int    s_ti[64];
-    __shared__ float  s_red[192];
-    __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
-    constexpr int     FJ_CAP = 16;
-    __shared__ float  s_fj[FJ_CAP * 24];
-    __shared__ int    s_fjc[FJ_CAP];
-    int               nfj = 0;
-
-    const nbx_sci_t e     = a.sci[blockIdx.x];
-    const int       sci   = e.sci;
-    const int       ntype = a.ntype;
-    const bool      central = (e.shift == NBX_CENTRAL);
-
-    {
-        const int ai = sci * 64 + lane;
-        float4    xi = a.xq[ai];
-        xi.x += a.shift_vec[3 * e.shift + 0];
-        xi.y += a.shift_vec[3 * e.shift + 1];
-        xi.z += a.shift_vec[3 * e.shift + 2];
-        xi.w *= a.epsfac;
-        s_xqi[lane] = xi;
-        s_ti[lane]  = a.type[ai] * ntype;
-        if (NBFP_LDS)
-        {
-            for (int k = lane; k < ntype * ntype; k += 64) { s_nbfp[k] = a.nbfp[k]; }
-        }
-    }
-    __syncthreads();
-
-    float fix[8], fiy[8], fiz[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { fix[i] = 0; fiy[i] = 0; fiz[i] = 0; }
-
-    float E_lj = 0, E_el = 0;
-
-    if (ENER)
-    {
-        // self term once per diagonal entry (nbnxn_cuda_kernel.cuh:222-256); q is already
-        // multiplied by epsfac, so divide one factor out
-        if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
-        {
-            const float q  = s_xqi[lane].w;
-            const float q2 = q * q * a.inv_epsfac;
-            E_el = (EL == NBX_EL_RF) ? -0.5f * a.c_rf * q2 : -a.beta * 0.564189583547756f * q2;
-        }
-    }
-
-    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
-    {
-        unsigned       imask = a.cj4[j4].imei[0].imask | a.cj4[j4].imei[1].imask;
-        if (!PRUNE && imask == 0) { continue; }
-        const unsigned wexcl = a.excl[a.cj4[j4].imei[lane >> 5].excl_ind].pair[lane & 31];
-
-        for (int jm = 0; jm < 4; jm++)
-        {
-            if (!(imask & (0xffu << (jm * 8)))) { continue; }
-            const int    cj    = a.cj4[j4].cj[jm];
-            const int    aj    = cj * 8 + tidxj;
-            const float4 xj    = a.xq[aj];
-            const int    typej = a.type[aj];
-            float        fjx = 0, fjy = 0, fjz = 0;
-            const unsigned ebits = wexcl >> (jm * 8);
-
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-            {
-                const unsigned bit = 1u << (jm * 8 + i);
-                if (imask & bit)
-                {
-                    const float4 xi = s_xqi[i * 8 + tidxi];
-                    const float  dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                    float        r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    if (PRUNE)
-                    {
-                        // a cluster pair with no atom pair inside rlist leaves the list
-                        // (nbnxn_cuda_kernel.cuh:332-340); wave-wide, so both halves agree
-                        if (!__any(r2 < a.rlist2)) { imask &= ~bit; }
-                    }
-                    const float int_bit = (ebits >> i) & 1u ? 1.0f : 0.0f;
-                    // cut-off, and on the diagonal cluster pair only j > i (:346-347)
-                    const bool  diag = central && (cj == sci * 8 + i);
-                    if (r2 < a.rc2 && (!diag || tidxj > tidxi))
-                    {
-                        float c6, c12;
-                        if (NBFP_LDS)
-                        {
-                            const float2 c = s_nbfp[s_ti[i * 8 + tidxi] + typej];
-                            c6 = c.x; c12 = c.y;
-                        }
-                        else
-                        {
-                            const float2 c = a.nbfp[s_ti[i * 8 + tidxi] + typej];
-                            c6 = c.x; c12 = c.y;
-                        }
-                        r2 = fmaf(1.0f - int_bit, NBX_AVOID_SING_R2_INC, r2);
-                        const float inv_r  = __builtin_amdgcn_rsqf(r2);
-                        const float inv_r2 = inv_r * inv_r;
-                        const float inv_r6 = inv_r2 * inv_r2 * inv_r2 * int_bit;
-                        float       F      = inv_r6 * fmaf(c12, inv_r6, -c6) * inv_r2;
-                        const float qq     = xi.w * xj.w;
-                        if (ENER)
-                        {
-                            E_lj += int_bit * (c12 * fmaf(inv_r6, inv_r6, a.rep_cpot) * (1.0f / 12.0f)
-                                               - c6 * (inv_r6 + a.disp_cpot) * (1.0f / 6.0f));
-                        }
-                        if (EL == NBX_EL_RF)
-                        {
-                            F = fmaf(qq, fmaf(int_bit, inv_r2 * inv_r, -a.two_k_rf), F);
-                            if (ENER) { E_el += qq * (fmaf(int_bit, inv_r, 0.5f * a.two_k_rf * r2) - a.c_rf); }
-                        }
-                        else
-                        {
-                            F = fmaf(qq, fmaf(int_bit, inv_r2 * inv_r, pme_corr_f(a.beta2 * r2) * a.beta3), F);
-                            if (ENER)
-                            {
-                                E_el += qq * (int_bit * (inv_r - a.sh_ewald) - a.beta * pme_corr_v(a.beta2 * r2));
-                            }
-                        }
-                        fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
-                        fix[i] = fmaf(dx, F, fix[i]); fiy[i] = fmaf(dy, F, fiy[i]); fiz[i] = fmaf(dz, F, fiz[i]);
-                    }
-                }
-            }
-
-            // j-force: sum over the 8 i-lanes, then lanes i = 0,1,2 add x,y,z: 24 lanes,
-            // 96 contiguous bytes, one atomic instruction
-            fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
-            const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
-            if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
-            if (lane == 0) { s_fjc[nfj] = cj; }
-            nfj++;
-        }
-
-        if (PRUNE)
-        {
-            if (lane == 0)
-            {
-                a.cj4[j4].imei[0].imask = imask;
-                a.cj4[j4].imei[1].imask = imask;
-            }
-        }
-        if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
-    }
-    if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
-
-    // i-forces: reduce-scatter over the 8 j-lanes (lane bits 5,4,3); lane (j,i) ends up
-    // with the total of i-cluster j, atom i, i.e. of atom sci*64 + lane
-    float rx, ry, rz;
-    {
-        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-        float      gx[4], gy[4], gz[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            gx[k] = (h5 ? fix[k + 4] : fix[k]) + __shfl_xor(h5 ? fix[k] : fix[k + 4], 32);
-            gy[k] = (h5 ? fiy[k + 4] : fiy[k]) + __shfl_xor(h5 ? fiy[k] : fiy[k + 4], 32);
-            gz[k] = (h5 ? fiz[k + 4] : fiz[k]) + __shfl_xor(h5 ? fiz[k] : fiz[k + 4], 32);
-        }
-        float hx[2], hy[2], hz[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-        {
-            hx[k] = (h4 ? gx[k + 2] : gx[k]) + __shfl_xor(h4 ? gx[k] : gx[k + 2], 16);
-            hy[k] = (h4 ? gy[k + 2] : gy[k]) + __shfl_xor(h4 ? gy[k] : gy[k + 2], 16);
-            hz[k] = (h4 ? gz[k + 2] : gz[k]) + __shfl_xor(h4 ? gz[k] : gz[k + 2], 16);
-        }
-        rx = (h3 ? hx[1] : hx[0]) + __shfl_xor(h3 ? hx[0] : hx[1], 8);
-        ry = (h3 ? hy[1] : hy[0]) + __shfl_xor(h3 ? hy[0] : hy[1], 8);
-        rz = (h3 ? hz[1] : hz[0]) + __shfl_xor(h3 ? hz[0] : hz[1], 8);
-    }
-    s_red[lane * 3 + 0] = rx;
-    s_red[lane * 3 + 1] = ry;
-    s_red[lane * 3 + 2] = rz;
-    __syncthreads();
-    {
-        float *fi = a.f + (size_t)sci * 192;
-        atomicAdd(&fi[lane], s_red[lane]);
-        atomicAdd(&fi[lane + 64], s_red[lane + 64]);
-        atomicAdd(&fi[lane + 128], s_red[lane + 128]);
-    }
-
-    if (ENER)
-    {
-        // per-entry partials: shift force (not for the central shift, whose virial
-        // contribution is zero: nbnxn_cuda_kernel.cuh:261-265) and the two energies
-        const float sx = central ? 0.0f : wave_sum(rx);
-        const float sy = central ? 0.0f : wave_sum(ry);
-        const float sz = central ? 0.0f : wave_sum(rz);
-        E_lj = wave_sum(E_lj);
-        E_el = wave_sum(E_el);
-        // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
-        float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
-        if (lane < 3)
-        {
-            if (!central) { atomicAdd(&slot[2 + 3 * e.shift + lane], lane == 0 ? sx : (lane == 1 ? sy : sz)); }
-        }
-        else if (lane < 5)
-        {
-            atomicAdd(&slot[lane - 3], lane == 3 ? E_lj : E_el);
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------
-// Variant 2: i-atoms live in registers for the whole entry (each lane only ever touches
-// the 8 i-atoms {8*ci + iatom}), the cut-off is applied by select instead of a divergent
-// branch, cj4 groups without exclusion words take a path with no interaction-bit
-// arithmetic, and the four j-clusters of a cj4 group are fetched in one batch.
-// ---------------------------------------------------------------------------------------
-template <int EL, bool ENER, bool PRUNE, bool EXCL>
-__device__ __forceinline__ void pair_v2(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
-                                        const float2 c, const unsigned ebit, const bool allowed,
-                                        float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
-                                        float &E_lj, float &E_el, bool &any_in_rlist)
-{
-    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-    float       r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    if (PRUNE) { any_in_rlist = __any(r2 < a.rlist2); }
-    bool cond = r2 < a.rc2;
-    if (EXCL) { cond = cond && allowed; }
-    float int_bit = 1.0f;
-    if (EXCL)
-    {
-        int_bit = ebit ? 1.0f : 0.0f;
-        r2      = fmaf(1.0f - int_bit, NBX_AVOID_SING_R2_INC, r2);
-    }
-    const float inv_r  = __builtin_amdgcn_rsqf(r2);
-    const float inv_r2 = inv_r * inv_r;
-    float       inv_r6 = inv_r2 * inv_r2 * inv_r2;
-    if (EXCL) { inv_r6 *= int_bit; }
-    float       F  = inv_r6 * fmaf(c.y, inv_r6, -c.x) * inv_r2;
-    const float qq = xi.w * xj.w;
-    const float inv_r3 = EXCL ? int_bit * inv_r2 * inv_r : inv_r2 * inv_r;
-    if (EL == NBX_EL_RF) { F = fmaf(qq, inv_r3 - a.two_k_rf, F); }
-    else { F = fmaf(qq, fmaf(pme_corr_f(a.beta2 * r2), a.beta3, inv_r3), F); }
-    F = cond ? F : 0.0f;
-    if (ENER)
-    {
-        float elj = c.y * fmaf(inv_r6, inv_r6, a.rep_cpot) * (1.0f / 12.0f) - c.x * (inv_r6 + a.disp_cpot) * (1.0f / 6.0f);
-        float eel;
-        if (EL == NBX_EL_RF)
-        {
-            eel = qq * ((EXCL ? int_bit * inv_r : inv_r) + 0.5f * a.two_k_rf * r2 - a.c_rf);
-        }
-        else
-        {
-            const float bv = a.beta * pme_corr_v(a.beta2 * r2);
-            eel = EXCL ? qq * (int_bit * (inv_r - a.sh_ewald) - bv) : qq * (inv_r - a.sh_ewald - bv);
-        }
-        if (EXCL) { elj *= int_bit; }
-        E_lj += cond ? elj : 0.0f;
-        E_el += cond ? eel : 0.0f;
-    }
-    fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
-    fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
-}
-
-// one cj4 group as a wave holds it: the four j-atoms of this lane, the lane's exclusion
-// word, and the wave-uniform list fields
-struct nbx_jbatch_t {
-    float4   xj[4];
-    int      tj[4];
-    unsigned wexcl;
-    unsigned imask;
-    int      cj[4];
-    bool     has_excl;
-};
-
-__device__ __forceinline__ void load_jbatch(const nbx_kernel_view_t &a, int j4, int lane, int tidxj, nbx_jbatch_t &b)
-{
-    const nbx_cj4_t *g = a.cj4 + j4;
-    b.imask = g->imei[0].imask | g->imei[1].imask;
-    const int ei0 = g->imei[0].excl_ind, ei1 = g->imei[1].excl_ind;
-    b.has_excl = (ei0 | ei1) != 0;
-    b.wexcl = 0xffffffffu;
-    if (b.has_excl) { b.wexcl = a.excl[lane < 32 ? ei0 : ei1].pair[lane & 31]; }
-#pragma unroll
-    for (int jm = 0; jm < 4; jm++)
-    {
-        // slots without interaction bits hold undefined j-clusters: read cluster 0 instead
-        b.cj[jm] = (b.imask >> (8 * jm)) & 0xffu ? g->cj[jm] : 0;
-        b.xj[jm] = a.xq[b.cj[jm] * 8 + tidxj];
-        b.tj[jm] = a.type[b.cj[jm] * 8 + tidxj];
-    }
-}
-
-template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V2_WAVES, 8))) nbnxn_kernel_v2(NBX_KERNEL_PARAMS)
-{
-    NBX_KERNEL_ARGS_FROM_PARAMS
-    const int lane  = threadIdx.x;
-    const int tidxi = lane & 7;
-    const int tidxj = lane >> 3;
-
-    __shared__ float4 s_xqi[64];
-    __shared__ int    s_ti[64];
-    __shared__ float  s_red[192];
-    // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
-    __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
-    constexpr int     FJ_CAP = 64;
-    __shared__ float  s_fj[FJ_CAP * 24];
-    __shared__ int    s_fjc[FJ_CAP];
-    int               nfj = 0;
-
-    const nbx_sci_t e     = a.sci[blockIdx.x];
-    const int       sci   = e.sci;
-    const int       ntype = a.ntype;
-    const bool      central = (e.shift == NBX_CENTRAL);
-
-#ifdef NBX_STAMPS
-    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long stampc0 = __builtin_amdgcn_s_memtime();
-    unsigned long long stamp_wait = 0, stamp_loop0 = 0, stamp_loop1 = 0;
-#endif
-    nbx_jbatch_t cur;
-    if (e.cj4_ind_start < e.cj4_ind_end) { load_jbatch(a, e.cj4_ind_start, lane, tidxj, cur); }
-
-    {
-        const int ai = sci * 64 + lane;
-        float4    x  = a.xq[ai];
-        x.x += a.shift_vec[3 * e.shift + 0];
-        x.y += a.shift_vec[3 * e.shift + 1];
-        x.z += a.shift_vec[3 * e.shift + 2];
-        x.w *= a.epsfac;
-        s_xqi[lane] = x;
-        s_ti[lane]  = a.type[ai];
-        if (NBFP_LDS)
-        {
-            for (int k = lane; k < ntype * ntype; k += 64)
-            {
-                const int t_i = k / ntype, t_j = k - t_i * ntype;
-                s_nbfp[t_j * MAX_LDS_TYPES + t_i] = a.nbfp[k];
-            }
-        }
-    }
-    __syncthreads();
-
-    // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
-    // their types are packed one per byte (LDS path: as byte offsets type*8 into a table row)
-    float4   xi[8];
-    unsigned tlo = 0, thi = 0;
-    float    fix[8], fiy[8], fiz[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-    {
-        xi[i] = s_xqi[i * 8 + tidxi];
-        const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? 8u : 1u);
-        if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
-        fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
-    }
-
-    float E_lj = 0, E_el = 0;
-    if (ENER)
-    {
-        if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
-        {
-            const float q  = s_xqi[lane].w;
-            const float q2 = q * q * a.inv_epsfac;
-            E_el = (EL == NBX_EL_RF) ? -0.5f * a.c_rf * q2 : -a.beta * 0.564189583547756f * q2;
-        }
-    }
-
-    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
-    {
-#ifdef NBX_STAMPS
-        {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long ta = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long tb = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stamp_wait += tb - ta;
-            if (stamp_loop0 == 0) { stamp_loop0 = ta; }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-        // software pipeline: the next group's list words and j-atoms are requested before
-        // this group's arithmetic starts
-        nbx_jbatch_t nxt;
-        if (j4 + 1 < e.cj4_ind_end) { load_jbatch(a, j4 + 1, lane, tidxj, nxt); }
-
-        unsigned imask = cur.imask;
-#pragma unroll
-        for (int jm = 0; jm < 4; jm++)
-        {
-            if (!(imask & (0xffu << (jm * 8)))) { continue; }
-            const int   cj  = cur.cj[jm];
-            const char *row = reinterpret_cast<const char *>(s_nbfp) + cur.tj[jm] * (MAX_LDS_TYPES * 8);
-            float       fjx = 0, fjy = 0, fjz = 0;
-#define NBX_LJ_PARAMS(i)                                                                              \
-    const unsigned tb_ = (((i) < 4 ? tlo : thi) >> (8 * ((i)&3))) & 0xffu;                             \
-    const float2   c   = NBFP_LDS ? *reinterpret_cast<const float2 *>(row + tb_) : a.nbfp[tb_ * ntype + cur.tj[jm]];
-            if (cur.has_excl)
-            {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                {
-                    const unsigned bit = 1u << (jm * 8 + i);
-                    if (imask & bit)
-                    {
-                        NBX_LJ_PARAMS(i)
-                        const bool diag = central && (cj == sci * 8 + i);
-                        bool       any = true;
-                        pair_v2<EL, ENER, PRUNE, true>(a, xi[i], cur.xj[jm], c, cur.wexcl & bit, !diag || tidxj > tidxi,
-                                                       fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
-                        if (PRUNE && !any) { imask &= ~bit; }
-                    }
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                {
-                    const unsigned bit = 1u << (jm * 8 + i);
-                    if (imask & bit)
-                    {
-                        NBX_LJ_PARAMS(i)
-                        bool any = true;
-                        pair_v2<EL, ENER, PRUNE, false>(a, xi[i], cur.xj[jm], c, 1u, true,
-                                                        fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
-                        if (PRUNE && !any) { imask &= ~bit; }
-                    }
-                }
-            }
-#undef NBX_LJ_PARAMS
-            fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
-            const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
-            if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
-            if (lane == 0) { s_fjc[nfj] = cj; }
-            nfj++;
-        }
-
-        if (PRUNE)
-        {
-            if (lane == 0)
-            {
-                a.cj4[j4].imei[0].imask = imask;
-                a.cj4[j4].imei[1].imask = imask;
-            }
-        }
-        cur = nxt;
-        if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
-    }
-#ifdef NBX_STAMPS
-    __builtin_amdgcn_sched_barrier(0);
-    stamp_loop1 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
-
-    float rx, ry, rz;
-    {
-        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-        float      gx[4], gy[4], gz[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            gx[k] = (h5 ? fix[k + 4] : fix[k]) + __shfl_xor(h5 ? fix[k] : fix[k + 4], 32);
-            gy[k] = (h5 ? fiy[k + 4] : fiy[k]) + __shfl_xor(h5 ? fiy[k] : fiy[k + 4], 32);
-            gz[k] = (h5 ? fiz[k + 4] : fiz[k]) + __shfl_xor(h5 ? fiz[k] : fiz[k + 4], 32);
-        }
-        float hx[2], hy[2], hz[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-        {
-            hx[k] = (h4 ? gx[k + 2] : gx[k]) + __shfl_xor(h4 ? gx[k] : gx[k + 2], 16);
-            hy[k] = (h4 ? gy[k + 2] : gy[k]) + __shfl_xor(h4 ? gy[k] : gy[k + 2], 16);
-            hz[k] = (h4 ? gz[k + 2] : gz[k]) + __shfl_xor(h4 ? gz[k] : gz[k + 2], 16);
-        }
-        rx = (h3 ? hx[1] : hx[0]) + __shfl_xor(h3 ? hx[0] : hx[1], 8);
-        ry = (h3 ? hy[1] : hy[0]) + __shfl_xor(h3 ? hy[0] : hy[1], 8);
-        rz = (h3 ? hz[1] : hz[0]) + __shfl_xor(h3 ? hz[0] : hz[1], 8);
-    }
-    s_red[lane * 3 + 0] = rx;
-    s_red[lane * 3 + 1] = ry;
-    s_red[lane * 3 + 2] = rz;
-    __syncthreads();
-    {
-        float *fi = a.f + (size_t)sci * 192;
-        atomicAdd(&fi[lane], s_red[lane]);
-        atomicAdd(&fi[lane + 64], s_red[lane + 64]);
-        atomicAdd(&fi[lane + 128], s_red[lane + 128]);
-    }
-
-    if (ENER)
-    {
-        const float sx = central ? 0.0f : wave_sum(rx);
-        const float sy = central ? 0.0f : wave_sum(ry);
-        const float sz = central ? 0.0f : wave_sum(rz);
-        E_lj = wave_sum(E_lj);
-        E_el = wave_sum(E_el);
-        // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
-        float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
-        if (lane < 3)
-        {
-            if (!central) { atomicAdd(&slot[2 + 3 * e.shift + lane], lane == 0 ? sx : (lane == 1 ? sy : sz)); }
-        }
-        else if (lane < 5)
-        {
-            atomicAdd(&slot[lane - 3], lane == 3 ? E_lj : E_el);
-        }
-    }
-#ifdef NBX_STAMPS
-    if (!ENER && lane == 0)
-    {
-        // diagnostic build only: wave lifetime and placement, into the (otherwise unused) partial record
-        unsigned long long *p = reinterpret_cast<unsigned long long *>(a.partial + (size_t)blockIdx.x * NBX_PARTIAL_STRIDE);
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p[0] = stamp0;
-        p[1] = __builtin_amdgcn_s_memrealtime();
-        p[2] = ((unsigned long long)xcc << 32) | hwid;
-        p[3] = (unsigned long long)(e.cj4_ind_end - e.cj4_ind_start);
-        const unsigned long long tend = __builtin_amdgcn_s_memtime();
-        // pack cycle counts (each < 2^21 here) into the spare words: prologue, loop, waits, epilogue
-        p[3] |= ((stamp_loop0 - stampc0) & 0xfffff) << 16 | ((stamp_loop1 - stamp_loop0) & 0xffffff) << 36;
-        p[2] |= 0;
-        reinterpret_cast<unsigned *>(a.partial)[(size_t)gridDim.x * NBX_PARTIAL_STRIDE + blockIdx.x * 2 + 0] = (unsigned)stamp_wait;
-        reinterpret_cast<unsigned *>(a.partial)[(size_t)gridDim.x * NBX_PARTIAL_STRIDE + blockIdx.x * 2 + 1] = (unsigned)(tend - stamp_loop1);
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------
-// Variant 2 (nbnxn_kernel_v3).  As nbnxn_kernel_v2, with three changes that came out of reading
-// the gfx950 code of that kernel:
+// The kernel.  Its shape came out of reading the gfx950 code of two earlier variants (kept in
+// the git history: i-atoms re-read from LDS per pair; separate pair bodies for groups with
+// and without exclusions, cj4-granular prefetch):
+//  * each lane keeps its eight i-atoms (one per i-cluster) and their 24 force accumulators
+//    in registers for the whole entry; the cut-off is a select, not a divergent branch;
 //  * ONE pair body for groups with and without exclusion words.  An if/else over two bodies
 //    merges the 24 i-force accumulators at its end; the register allocator then keeps two
 //    copies of them (24 more live registers, three moves per skipped pair, 24 per skipped
@@ -786,15 +205,15 @@ __device__ __forceinline__ float and_mask(const float v, const int m)
 }
 
 template <int EL, bool ENER, bool PRUNE>
-__device__ __forceinline__ void pair_v3(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
+__device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
                                         const float2 c, const unsigned wexcl, const int bitpos, const bool allowed,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
                                         float &E_lj, float &E_el, bool &any_in_rlist)
 {
     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
     const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    if (PRUNE) { any_in_rlist = __any(r2 < a.rlist2); }
-    const bool  cond = (r2 < a.rc2) && allowed;
+    if (PRUNE) { any_in_rlist = __any(r2 < a.k.rlist2); }
+    const bool  cond = (r2 < a.k.rc2) && allowed;
     // 0 for an excluded pair, all ones otherwise
     const int   m      = __builtin_amdgcn_sbfe((int)wexcl, bitpos, 1);
     const float inv_r  = __builtin_amdgcn_rsqf(r2);
@@ -806,23 +225,24 @@ __device__ __forceinline__ void pair_v3(const nbx_kernel_view_t &a, const float4
     // LJ + plain Coulomb vanish for excluded pairs; the reaction-field / Ewald correction stays
     const float t = and_mask(fmaf(qq, inv_r, lj6) * inv_r2, m);
     float       F, gv = 0.0f;
-    if (EL == NBX_EL_RF) { F = fmaf(qq, -a.two_k_rf, t); }
+    if (EL == NBX_EL_RF) { F = fmaf(qq, -a.k.two_k_rf, t); }
     else
     {
         float gf;
-        if (ENER) { pme_corr_fv(a.beta2 * r2, gf, gv); }
-        else { gf = pme_corr_f(a.beta2 * r2); }
-        F = fmaf(qq, gf * a.beta3, t);
+        // scaled coordinates: r2 is (beta r)^2 and qq carries beta^2
+        if (ENER) { pme_corr_fv(r2, gf, gv); }
+        else { gf = pme_corr_f(r2); }
+        F = fmaf(qq, gf, t);
     }
     F = cond ? F : 0.0f;
     if (ENER)
     {
         // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6 = c12 r^-12 - c6 r^-6
-        const float shift = fmaf(c.y, a.rep_cpot * (1.0f / 12.0f), c.x * (a.disp_cpot * (-1.0f / 6.0f)));
+        const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
         const float elj   = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
         float       eel;
-        if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.two_k_rf, r2, -a.c_rf)); }
-        else { eel = qq * fmaf(-a.beta, gv, and_mask(inv_r - a.sh_ewald, m)); }
+        if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf)); }
+        else { eel = qq * (and_mask(inv_r - a.k.sh, m) - gv); }
         E_lj += cond ? elj : 0.0f;
         E_el += cond ? eel : 0.0f;
     }
@@ -864,12 +284,13 @@ __device__ __forceinline__ void load_jslot(const nbx_kernel_view_t &a, int cj, i
 }
 
 template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS, int JM>
-__device__ __forceinline__ void jcluster_v3(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
+__device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
                                             const unsigned thi, float (&fix)[8], float (&fiy)[8], float (&fiz)[8],
                                             const nbx_jslot_t &s, const int cj, const unsigned wexcl,
                                             unsigned &imask, const bool central, const int sci, const int tidxi,
                                             const int tidxj, const int lane, const float2 *s_nbfp, float *s_fj,
-                                            int *s_fjc, int &nfj, float &E_lj, float &E_el)
+                                            int *s_fjc, int &nfj, float &E_lj, float &E_el, const float ox, const float oy,
+                                            const float oz)
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
     float2 c[8];
@@ -890,8 +311,12 @@ __device__ __forceinline__ void jcluster_v3(const nbx_kernel_view_t &a, const fl
         {
             const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
             c[i] = a.nbfp[tb * a.ntype + s.t];
+            if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; }
         }
     }
+    float4 xj = s.x;
+    // Ewald: coordinates relative to the entry's origin (an exact subtraction), then scaled by beta
+    if (EL != NBX_EL_RF) { xj.x = (xj.x - ox) * a.k.xscale; xj.y = (xj.y - oy) * a.k.xscale; xj.z = (xj.z - oz) * a.k.xscale; }
     float fjx = 0, fjy = 0, fjz = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -901,7 +326,7 @@ __device__ __forceinline__ void jcluster_v3(const nbx_kernel_view_t &a, const fl
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_v3<EL, ENER, PRUNE>(a, xi[i], s.x, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
+            pair_interaction<EL, ENER, PRUNE>(a, xi[i], xj, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
@@ -913,12 +338,12 @@ __device__ __forceinline__ void jcluster_v3(const nbx_kernel_view_t &a, const fl
     nfj++;
 }
 
-#ifndef NBX_V3_WAVES
-#define NBX_V3_WAVES 4
+#ifndef NBX_KERNEL_WAVES
+#define NBX_KERNEL_WAVES 4
 #endif
 
 template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_WAVES, 8))) nbnxn_kernel_v3(NBX_KERNEL_PARAMS)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KERNEL_WAVES, 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
 {
     NBX_KERNEL_ARGS_FROM_PARAMS
     const int lane  = threadIdx.x;
@@ -953,7 +378,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
         x.x += a.shift_vec[3 * e.shift + 0];
         x.y += a.shift_vec[3 * e.shift + 1];
         x.z += a.shift_vec[3 * e.shift + 2];
-        x.w *= a.epsfac;
+        x.w *= a.k.qscale;
         s_xqi[lane] = x;
         s_ti[lane]  = a.type[ai];
         if (NBFP_LDS)
@@ -961,7 +386,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
             for (int k = lane; k < ntype * ntype; k += 64)
             {
                 const int t_i = k / ntype, t_j = k - t_i * ntype;
-                s_nbfp[t_j * MAX_LDS_TYPES + t_i] = a.nbfp[k];
+                float2    c   = a.nbfp[k];
+                if (EL != NBX_EL_RF) { c.x *= a.k.c6scale; c.y *= a.k.c12scale; }
+                s_nbfp[t_j * MAX_LDS_TYPES + t_i] = c;
             }
         }
     }
@@ -969,6 +396,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
 
     // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
     // their types are packed one per byte (LDS path: as byte offsets type*8 into a table row)
+    // Ewald: the origin of the scaled coordinates is the entry's first (shifted) i-atom; scaling
+    // the raw coordinates instead would round at ulp(beta |x|) and cost ~1e-5 of force accuracy
+    float ox = 0, oy = 0, oz = 0;
+    if (EL != NBX_EL_RF)
+    {
+        const float4 o = s_xqi[0];
+        ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
+        oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
+        oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
+    }
     float4   xi[8];
     unsigned tlo = 0, thi = 0;
     float    fix[8], fiy[8], fiz[8];
@@ -976,6 +413,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
     for (int i = 0; i < 8; i++)
     {
         xi[i] = s_xqi[i * 8 + tidxi];
+        if (EL != NBX_EL_RF)
+        {
+            xi[i].x = (xi[i].x - ox) * a.k.xscale; xi[i].y = (xi[i].y - oy) * a.k.xscale; xi[i].z = (xi[i].z - oz) * a.k.xscale;
+        }
         const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? 8u : 1u);
         if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
         fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
@@ -986,16 +427,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
     {
         if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
         {
-            const float q  = s_xqi[lane].w;
-            const float q2 = q * q * a.inv_epsfac;
-            E_el = (EL == NBX_EL_RF) ? -0.5f * a.c_rf * q2 : -a.beta * 0.564189583547756f * q2;
+            // self term (nbnxn_cuda_kernel.cuh:239-262) in the scaled charges
+            const float q = s_xqi[lane].w;
+            E_el = a.k.self * q * q;
         }
     }
 
-#define NBX_V3_JCLUSTER(JM, SLOT)                                                                             \
-    jcluster_v3<EL, ENER, PRUNE, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
+#define NBX_JCLUSTER(JM, SLOT)                                                                             \
+    jcluster<EL, ENER, PRUNE, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
-                                               nfj, E_lj, E_el)
+                                               nfj, E_lj, E_el, ox, oy, oz)
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
     {
         // software pipeline: the next group's list words are requested before this group's
@@ -1007,13 +448,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
 
         unsigned imask = cur.imask;
         load_jslot(a, cur.cj[1], tidxj, sb);
-        NBX_V3_JCLUSTER(0, sa);
+        NBX_JCLUSTER(0, sa);
         load_jslot(a, cur.cj[2], tidxj, sa);
-        NBX_V3_JCLUSTER(1, sb);
+        NBX_JCLUSTER(1, sb);
         load_jslot(a, cur.cj[3], tidxj, sb);
-        NBX_V3_JCLUSTER(2, sa);
+        NBX_JCLUSTER(2, sa);
         load_jslot(a, nxt.cj[0], tidxj, sa);
-        NBX_V3_JCLUSTER(3, sb);
+        NBX_JCLUSTER(3, sb);
 
         if (PRUNE)
         {
@@ -1026,7 +467,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
         cur = nxt;
         if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
     }
-#undef NBX_V3_JCLUSTER
+#undef NBX_JCLUSTER
     if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
 
     float rx, ry, rz;
@@ -1068,8 +509,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
         const float sx = central ? 0.0f : wave_sum(rx);
         const float sy = central ? 0.0f : wave_sum(ry);
         const float sz = central ? 0.0f : wave_sum(rz);
-        E_lj = wave_sum(E_lj);
-        E_el = wave_sum(E_el);
+        E_lj = wave_sum(E_lj) * a.k.escale;
+        E_el = wave_sum(E_el) * a.k.escale;
         // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
         float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
         if (lane < 3)
@@ -1084,36 +525,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_V3_
 }
 
 template <int EL, bool ENER, bool PRUNE>
-void launch_flavour(const nbx_kernel_args_t &a, int nsci, int variant, hipStream_t stream)
+void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
 {
-    if (variant == 2)
-    {
-        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel_v3<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-        else { hipLaunchKernelGGL((nbnxn_kernel_v3<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-    }
-    else if (variant == 1)
-    {
-        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-        else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-    }
-    else
-    {
-        if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-        else { hipLaunchKernelGGL((nbnxn_kernel_v2<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-    }
+    if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
 }
 
 } // namespace
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
-                                int variant, hipStream_t stream)
+                                hipStream_t stream)
 {
     if (nsci <= 0) { return hipSuccess; }
 #define NBX_DISPATCH(EL)                                                                     \
-    if (ener) { if (prune) { launch_flavour<EL, true, true>(a, nsci, variant, stream); }              \
-                else       { launch_flavour<EL, true, false>(a, nsci, variant, stream); } }           \
-    else      { if (prune) { launch_flavour<EL, false, true>(a, nsci, variant, stream); }             \
-                else       { launch_flavour<EL, false, false>(a, nsci, variant, stream); } }
+    if (ener) { if (prune) { launch_flavour<EL, true, true>(a, nsci, stream); }              \
+                else       { launch_flavour<EL, true, false>(a, nsci, stream); } }           \
+    else      { if (prune) { launch_flavour<EL, false, true>(a, nsci, stream); }             \
+                else       { launch_flavour<EL, false, false>(a, nsci, stream); } }
     if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF) }
     else { NBX_DISPATCH(NBX_EL_EWALD_ANA) }
 #undef NBX_DISPATCH

@@ -1,0 +1,292 @@
+"""1-D slab domain decomposition of the Verlet nonbonded path, one process per GPU.
+
+The reference decomposes space (mdlib/domdec.c) and computes non-local pairs on the GPU in a
+second stream (sim_util.c:1012-1212: local launch, halo x, non-local launch, copy-backs,
+halo f).  The path's multi-GPU form here is the smallest scheme with the same data flow:
+
+  * z slabs of equal thickness, rank r owns z in [r Lz, (r+1) Lz); x and y stay periodic
+    inside the search, z is decomposed (no periodic shift along z: nbnxn_search.c:4906-4927);
+  * half shell: rank r imports the atoms of rank r+1 that lie within rlist above its upper
+    face (zone 1 of its grid) and computes home x halo pairs in the NON-LOCAL list; home x home
+    pairs are the LOCAL list.  Slabs must be thicker than rlist so that only neighbours interact;
+  * per step: halo coordinates travel DOWN (r -> r-1), halo forces travel UP (r -> r+1) and are
+    added to the owner's forces; {e_lj, e_el, fshift} are summed over ranks.
+
+Everything that moves between ranks is a torch tensor handed to torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests): `Domain` and
+`HaloExchange` work on CPU and GPU tensors alike.  `SlabRun` binds them to the HIP module
+(device buffers wrapped in place, local / non-local HIP streams); tests/test_dd_cpu.py binds
+them to the oracle instead.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import abi
+from . import system as sysmod
+from .host import NbnxnHost, PairList
+
+
+@dataclass
+class Domain:
+    rank: int
+    world: int
+    box: np.ndarray            # global box
+    lz: float                  # slab thickness
+    nhome: int                 # home atoms (caller order: home first, halo after)
+    nhalo: int
+    home_ids: np.ndarray       # global atom ids of the home atoms
+    halo_ids: np.ndarray       # global atom ids of the imported atoms, in arrival order
+    host: NbnxnHost
+    xq: np.ndarray             # [npad, 4] grid order, home grid first
+    type: np.ndarray           # [npad]
+    ntype: int
+    nbfp: np.ndarray
+    shift_vec: np.ndarray
+    pl_local: PairList
+    pl_nonlocal: PairList
+    npad: int
+    npad_local: int
+    send_slots: np.ndarray     # grid slots of the home atoms the lower neighbour imports
+    send_zshift: float         # added to their z on the way (periodic wrap at the bottom rank)
+    halo_slots: np.ndarray     # grid slots the imported atoms occupy here
+
+    @property
+    def pair_slots(self):
+        return (self.pl_local.nci_tot + self.pl_nonlocal.nci_tot) * 64
+
+    @property
+    def up(self):
+        return (self.rank + 1) % self.world
+
+    @property
+    def down(self):
+        return (self.rank - 1) % self.world
+
+
+def _staged(t):
+    """gloo moves host memory only: device tensors are staged through the host for it (the
+    one-GPU rehearsal of tests/test_gpu_dd.py); RCCL takes them as they are."""
+    return t is not None and t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _exchange(send, dst, recv, src):
+    """Ring step: everybody sends to `dst` and receives from `src` at once."""
+    if _staged(send) or _staged(recv):
+        hs = send.cpu() if send is not None else None
+        hr = torch.empty(recv.shape, dtype=recv.dtype) if recv is not None else None
+        _exchange(hs, dst, hr, src)
+        if recv is not None:
+            recv.copy_(hr)
+        return
+    ops = []
+    if send is not None and send.numel() > 0:
+        ops.append(dist.P2POp(dist.isend, send, dst))
+    if recv is not None and recv.numel() > 0:
+        ops.append(dist.P2POp(dist.irecv, recv, src))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
+    """Cuts rank `rank`'s slab out of the global system `glob` (every rank holds the synthetic
+    global topology; coordinates of imported atoms still arrive by message, as they would in a
+    run), grids home and halo zones, and builds both lists."""
+    if world < 2:
+        raise ValueError("domain decomposition needs at least 2 ranks")
+    box = np.asarray(glob.box, dtype=np.float32)
+    lz = float(box[2]) / world
+    if lz <= ip.rlist:
+        raise ValueError(f"slab thickness {lz:.3f} nm must exceed rlist {ip.rlist:.3f} nm")
+    z = glob.x[:, 2].astype(np.float64)
+    owner = np.clip(np.floor(z / lz).astype(np.int64), 0, world - 1)
+    home_ids = np.nonzero(owner == rank)[0]
+    nhome = len(home_ids)
+    x_home = glob.x[home_ids]
+
+    # what the lower neighbour imports from me: my atoms within rlist of my lower face
+    zrel = x_home[:, 2] - np.float32(rank * lz)
+    down_sel = np.nonzero(zrel < ip.rlist)[0]
+    send_zshift = float(box[2]) if rank == 0 else 0.0
+    up, down = (rank + 1) % world, (rank - 1) % world
+
+    n_send = torch.tensor([len(down_sel)], dtype=torch.int64, device=device)
+    n_recv = torch.zeros(1, dtype=torch.int64, device=device)
+    _exchange(n_send, down, n_recv, up)
+    nhalo = int(n_recv.item())
+    ids_send = torch.from_numpy(home_ids[down_sel].astype(np.int64)).to(device)
+    xs = x_home[down_sel].copy()
+    xs[:, 2] += np.float32(send_zshift)
+    x_send = torch.from_numpy(xs).to(device)
+    ids_recv = torch.zeros(nhalo, dtype=torch.int64, device=device)
+    x_recv = torch.zeros((nhalo, 3), dtype=torch.float32, device=device)
+    _exchange(ids_send, down, ids_recv, up)
+    _exchange(x_send, down, x_recv, up)
+    halo_ids = ids_recv.cpu().numpy()
+    x_halo = x_recv.cpu().numpy()
+
+    # grids: zone 0 = home slab, zone 1 = the rlist-thick layer above it
+    host = NbnxnHost(box, pbc_shift_dim=(1, 1, 0))
+    z0 = rank * lz
+    host.put_on_grid(0, (0.0, 0.0, z0), (box[0], box[1], z0 + lz), 0, x_home)
+    if nhalo > 0:
+        host.put_on_grid(1, (0.0, 0.0, z0 + lz), (box[0], box[1], z0 + lz + ip.rlist), nhome, x_halo)
+    ids_all = np.concatenate([home_ids, halo_ids])
+    x_all = np.concatenate([x_home, x_halo]).astype(np.float32)
+    ntype = glob.ntype + 1
+    xq, typ = host.set_atomdata(ntype, glob.type[ids_all], glob.q[ids_all])
+    host.copy_x_to_xq(x_all, xq)
+
+    # topology exclusions in local numbering; partners that are not on this rank drop out
+    g2l = np.full(glob.natoms, -1, dtype=np.int64)
+    g2l[ids_all] = np.arange(len(ids_all))
+    cnt = (glob.excl_index[1:] - glob.excl_index[:-1])[ids_all]
+    starts = glob.excl_index[:-1][ids_all]
+    flat = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+    partners = g2l[glob.excl_a[flat]]
+    row = np.repeat(np.arange(len(ids_all)), cnt)
+    keep = partners >= 0
+    row, partners = row[keep], partners[keep]
+    excl_index = np.zeros(len(ids_all) + 1, dtype=np.int32)
+    np.add.at(excl_index, row + 1, 1)
+    excl_index = np.cumsum(excl_index).astype(np.int32)
+    excl_a = partners.astype(np.int32)
+
+    pl_local = host.make_pairlist(abi.LOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
+    pl_nonlocal = host.make_pairlist(abi.NONLOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
+    cell = host.cell_index()
+    return Domain(rank=rank, world=world, box=box, lz=lz, nhome=nhome, nhalo=nhalo, home_ids=home_ids,
+                  halo_ids=halo_ids, host=host, xq=xq, type=typ, ntype=ntype, nbfp=glob.nbfp(),
+                  shift_vec=host.shift_vec(), pl_local=pl_local, pl_nonlocal=pl_nonlocal,
+                  npad=len(xq), npad_local=host.natoms_padded_local,
+                  send_slots=cell[down_sel].astype(np.int64), send_zshift=send_zshift,
+                  halo_slots=cell[nhome:nhome + nhalo].astype(np.int64))
+
+
+class HaloExchange:
+    """The per-step messages, on tensors that alias the engine's coordinate and force arrays:
+    xq_t [npad, 4] and f_t [npad, 3] (grid order)."""
+
+    def __init__(self, dom, xq_t, f_t):
+        dev = xq_t.device
+        self.dom, self.xq_t, self.f_t = dom, xq_t, f_t
+        self.send_slots = torch.from_numpy(dom.send_slots).to(dev)
+        self.halo_slots = torch.from_numpy(dom.halo_slots).to(dev)
+        self.zshift = torch.tensor([0.0, 0.0, dom.send_zshift, 0.0], dtype=torch.float32, device=dev)
+        self.x_out = torch.zeros((len(dom.send_slots), 4), dtype=torch.float32, device=dev)
+        self.x_in = torch.zeros((dom.nhalo, 4), dtype=torch.float32, device=dev)
+        self.f_out = torch.zeros((dom.nhalo, 3), dtype=f_t.dtype, device=dev)
+        self.f_in = torch.zeros((len(dom.send_slots), 3), dtype=f_t.dtype, device=dev)
+        # forces that come back across the periodic wrap count towards the shift force of
+        # (0, 0, +1), as dd_move_f does for shifted pulses (mdlib/domdec.c:1046-1068): the
+        # virial needs  box_z (x) sum of those forces
+        self.wrap_shift = 5 * (3 * (1 + 1) + 0 + 1) + 0 + 2 if dom.send_zshift != 0.0 else -1
+        self.fshift_wrap = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    def send_x(self):
+        """home {x,y,z,q} rows the lower neighbour imports go down; mine arrive from above."""
+        torch.index_select(self.xq_t, 0, self.send_slots, out=self.x_out)
+        self.x_out += self.zshift
+        _exchange(self.x_out, self.dom.down, self.x_in, self.dom.up)
+        self.xq_t.index_copy_(0, self.halo_slots, self.x_in)
+
+    def return_f(self):
+        """forces on imported atoms go back up to their owner, who adds them."""
+        torch.index_select(self.f_t, 0, self.halo_slots, out=self.f_out)
+        _exchange(self.f_out, self.dom.up, self.f_in, self.dom.down)
+        self.f_t.index_add_(0, self.send_slots, self.f_in)
+        if self.wrap_shift >= 0:
+            self.fshift_wrap = self.f_in.to(torch.float64).sum(0)
+
+
+def fold_and_reduce(out_t, halo=None):
+    """{e_lj, e_el, fshift[45][3]} summed over the accumulation slots in double, then over ranks."""
+    e = out_t.view(-1, abi.OUT_STRIDE).to(torch.float64).sum(0)
+    if halo is not None and halo.wrap_shift >= 0:
+        e[2 + 3 * halo.wrap_shift:5 + 3 * halo.wrap_shift] += halo.fshift_wrap
+    if _staged(e):
+        h = e.cpu()
+        dist.all_reduce(h)
+        e.copy_(h)
+    else:
+        dist.all_reduce(e)
+    return e
+
+
+class _DevArray:
+    """A raw device pointer as a __cuda_array_interface__ object, so torch aliases the HIP module's buffers."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class SlabRun:
+    """Weak-scaling workload of bench.py: water_box(tx, ty, tz * world) cut into `world` z slabs."""
+
+    def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None):
+        from . import gpu
+        self.flags = flags
+        self.dev = torch.device("cuda", local_rank)
+        glob = sysmod.water_box(tiles[0], tiles[1], tiles[2] * world, model=model)
+        self.natoms_global = glob.natoms
+        self.nb = nb = gpu.NbnxnHip(local_rank, local_and_nonlocal=True)
+        mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced
+        self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb)
+        nb.init_const(ip, dom.ntype, dom.nbfp)
+        nb.init_atomdata(dom.npad, dom.npad_local, dom.ntype, dom.type)
+        nb.upload_shiftvec(dom.shift_vec)
+        nb.init_pairlist(dom.pl_local, abi.LOCAL)
+        nb.init_pairlist(dom.pl_nonlocal, abi.NONLOCAL)
+        assert nb.verify_pairlist(dom.pl_local, abi.LOCAL) == 0
+        assert nb.verify_pairlist(dom.pl_nonlocal, abi.NONLOCAL) == 0
+        # first pass the reference way: host xq in, forces out, both lists pruned, streams drained
+        self.f_first, self.e_first = nb.compute_both(dom.xq, flags)
+        d_xq, d_f, _ = nb.device_buffers()
+        d_out, nslots, stride = nb.output_slots()
+        assert (nslots, stride) == (abi.OUT_SLOTS, abi.OUT_STRIDE)
+        self.xq_t = torch.as_tensor(_DevArray(d_xq, (dom.npad, 4)), device=self.dev)
+        self.f_t = torch.as_tensor(_DevArray(d_f, (dom.npad, 3)), device=self.dev)
+        self.out_t = torch.as_tensor(_DevArray(d_out, (abi.OUT_SLOTS * abi.OUT_STRIDE,)), device=self.dev)
+        self.halo = HaloExchange(dom, self.xq_t, self.f_t)
+        self.s_loc = torch.cuda.ExternalStream(nb.stream(abi.LOCAL), device=self.dev)
+        self.s_nl = torch.cuda.ExternalStream(nb.stream(abi.NONLOCAL), device=self.dev)
+        self.energies = None
+
+    @property
+    def pair_slots_local(self):
+        return self.dom.pair_slots
+
+    def describe(self):
+        d = self.dom
+        return {"atoms_rank0": d.nhome, "halo_atoms_rank0": d.nhalo, "nsci_local": d.pl_local.nsci,
+                "nsci_nonlocal": d.pl_nonlocal.nsci, "cluster_pairs_rank0": d.pl_local.nci_tot + d.pl_nonlocal.nci_tot}
+
+    def step(self, ev=None):
+        nb, fl = self.nb, self.flags
+        nb.clear_outputs(fl)                              # local stream
+        if ev:
+            ev[0].record(self.s_loc)
+        nb.launch_kernel_resident(fl, abi.LOCAL)          # local stream; non-local waits for the clear only
+        if ev:
+            ev[1].record(self.s_loc)
+        with torch.cuda.stream(self.s_nl):
+            self.halo.send_x()                            # overlaps the local kernel
+        nb.launch_kernel_resident(fl, abi.NONLOCAL)       # non-local stream, after the halo arrived
+        with torch.cuda.stream(self.s_nl):
+            self.s_nl.wait_stream(self.s_loc)             # owner-side adds and the fold see the local kernel done
+            self.halo.return_f()
+            if fl & abi.FORCE_VIRIAL:
+                self.energies = fold_and_reduce(self.out_t, self.halo)
+        self.s_loc.wait_stream(self.s_nl)
+
+    def forces_home(self):
+        """home forces in caller order of this rank's home atoms (after a step)."""
+        torch.cuda.synchronize(self.dev)
+        fnb = self.f_t.cpu().numpy()
+        f = np.zeros((self.dom.nhome + self.dom.nhalo, 3), dtype=np.float32)
+        self.dom.host.add_f(fnb, f)
+        return f[:self.dom.nhome]

@@ -67,6 +67,8 @@ def load():
     lib.nbnxn_hip_last_kernel_ms.argtypes = [vp, ci]
     lib.nbnxn_hip_last_kernel_ms.restype = cf
     lib.nbnxn_hip_set_prune.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_get_output_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
+    lib.nbnxn_hip_set_timing.argtypes = [vp, ci]
     lib.nbnxn_hip_set_kernel_variant.argtypes = [vp, ci]
     # the host runtime raises instead of aborting the interpreter (gmx_fatal would abort)
     lib.nbnxn_hip_set_abort_on_error(0)
@@ -173,6 +175,9 @@ class NbnxnHip:
     def set_kernel_variant(self, v):
         self._chk(self.lib.nbnxn_hip_set_kernel_variant(self.h, v))
 
+    def set_timing(self, on):
+        self._chk(self.lib.nbnxn_hip_set_timing(self.h, int(on)))
+
     def set_prune(self, iloc, on):
         self._chk(self.lib.nbnxn_hip_set_prune(self.h, iloc, int(on)))
 
@@ -204,6 +209,11 @@ class NbnxnHip:
         self._chk(self.lib.nbnxn_hip_get_device_buffers(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def output_slots(self):
+        a, n, st = C.c_void_p(), C.c_int(), C.c_int()
+        self._chk(self.lib.nbnxn_hip_get_output_slots(self.h, C.byref(a), C.byref(n), C.byref(st)))
+        return a.value, n.value, st.value
+
     def stream(self, iloc=abi.LOCAL):
         return self.lib.nbnxn_hip_get_stream(self.h, iloc)
 
@@ -221,4 +231,20 @@ class NbnxnHip:
         self.launch_kernel(xq, flags, iloc)
         self.launch_cpyback(f, flags, iloc)
         self.wait_gpu(flags, iloc, e_lj, e_el, fshift)
+        return f, (float(e_lj[0]), float(e_el[0]), fshift)
+
+    def compute_both(self, xq, flags=0):
+        """One step with local and non-local work in the reference's order (sim_util.c:1012-1212,
+        1440-1486): both launches, non-local copy-back and wait first, then local."""
+        f = np.zeros((self.natoms, 3), dtype=np.float32)
+        e_lj = np.zeros(1, dtype=np.float32)
+        e_el = np.zeros(1, dtype=np.float32)
+        fshift = np.zeros((abi.SHIFTS, 3), dtype=np.float32)
+        self.clear_outputs(flags | abi.FORCE_VIRIAL)
+        self.launch_kernel(xq, flags, abi.LOCAL)
+        self.launch_kernel(xq, flags, abi.NONLOCAL)
+        self.launch_cpyback(f, flags, abi.NONLOCAL)
+        self.launch_cpyback(f, flags, abi.LOCAL)
+        self.wait_gpu(flags, abi.NONLOCAL)
+        self.wait_gpu(flags, abi.LOCAL, e_lj, e_el, fshift)
         return f, (float(e_lj[0]), float(e_el[0]), fshift)

@@ -383,6 +383,12 @@ int nbnxn_hip_wait_gpu_flat(nbnxn_hip_ptr_t nb, int flags, int aloc,
 /* device addresses of the xq (float4), f (float[3]) and atom-type arrays */
 int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, void **d_type);
 
+/* device address and shape of the energy / shift-force accumulation slots: float
+ * [nslots][stride], each slot {e_lj, e_el, fshift[45][3], padding}; the kernels add into
+ * slot (entry index mod nslots), read_outputs / wait_gpu sum the slots in double.  For
+ * resident callers that reduce them on the device (the multi-GPU all-reduce). */
+int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, int *stride);
+
 /* the HIP stream (hipStream_t) of a locality, as an opaque pointer */
 void *nbnxn_hip_get_stream(nbnxn_hip_ptr_t nb, int iloc);
 
@@ -412,6 +418,12 @@ float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc);
 /* arms (1) or disarms (0) the pruning flavour for the next launch of a locality;
  * the reference arms it in init_pairlist and disarms it in wait_gpu. */
 int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune);
+
+/* switches the module's HIP-event timing (wallclock_gpu_t accounting) on or off; the default
+ * follows the reference's bDoTime (nbnxn_cuda_data_mgmt.cu:626-627): on with one stream unless
+ * GMX_DISABLE_HIP_TIMING is set, off with two.  Each timed launch carries two event records
+ * (~7 us of device time on MI355X), so resident callers that launch every ~100 us turn it off. */
+int nbnxn_hip_set_timing(nbnxn_hip_ptr_t nb, int on);
 
 /* kernel tuning knob for benchmarking: 0 = default variant */
 int nbnxn_hip_set_kernel_variant(nbnxn_hip_ptr_t nb, int variant);

@@ -1,0 +1,102 @@
+"""The multi-GPU form of the path on CPU: world_size 2 and 3 over gloo, with the oracle in place
+of the HIP kernels.  What is under test is everything bench.py --gpus N adds around the
+kernel: the slab cut, the halo zone and its grid, local / non-local lists, exclusions across
+the cut, the per-step coordinate and force messages, the periodic wrap at the bottom rank and
+the energy / shift-force reduction (gromacs-cosmo_amd/dd.py).  Reference: the same global
+system as ONE domain through the same oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, model, min_ci_balanced, ret):
+    import gromacs_cosmo_amd as g
+    from gromacs_cosmo_amd import abi, dd
+    import oracle as O
+    from util import virial_from
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
+        glob = g.system.water_box(2, 2, 2 * world, model=model)
+        dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced)
+        xq_t = torch.from_numpy(dom.xq)                 # aliases dom.xq
+        f_t = torch.zeros((dom.npad, 3), dtype=torch.float64)
+        halo = dd.HaloExchange(dom, xq_t, f_t)
+        # the imported coordinates must really arrive by message: wreck them first
+        want = dom.xq[dom.halo_slots].copy()
+        dom.xq[dom.halo_slots, :3] = 1e6
+        halo.send_x()
+        assert np.array_equal(dom.xq[dom.halo_slots], want)
+
+        o_l = O.kernel_gpu_list(dom.xq, dom.type, dom.ntype, dom.nbfp, dom.shift_vec, dom.pl_local, ip)
+        o_n = O.kernel_gpu_list(dom.xq, dom.type, dom.ntype, dom.nbfp, dom.shift_vec, dom.pl_nonlocal, ip)
+        f_t += torch.from_numpy(np.asarray(o_l["f"], dtype=np.float64) + np.asarray(o_n["f"], dtype=np.float64))
+        # non-local entries only touch home i-atoms and halo j-atoms
+        assert dom.pl_nonlocal.nsci > 0 and dom.pl_nonlocal.sci["sci"].max() * 64 < dom.npad_local
+        halo.return_f()
+        out = torch.zeros((abi.OUT_SLOTS, abi.OUT_STRIDE), dtype=torch.float64)
+        out[0, 0] = o_l["Vvdw"] + o_n["Vvdw"]
+        out[0, 1] = o_l["Vc"] + o_n["Vc"]
+        out[0, 2:2 + 135] = torch.from_numpy((np.asarray(o_l["fshift"]) + np.asarray(o_n["fshift"])).reshape(-1))
+        e = dd.fold_and_reduce(out.view(-1), halo).numpy()
+
+        fnb = f_t.numpy().astype(np.float32)
+        f_home = np.zeros((dom.nhome + dom.nhalo, 3), dtype=np.float32)
+        dom.host.add_f(fnb, f_home)
+        # virial pieces of this rank: home atoms only (the imported ones gave their forces back)
+        x_home = glob.x[dom.home_ids].astype(np.float64)
+        xf = x_home.T @ f_home[:dom.nhome].astype(np.float64)
+        xf_t = torch.from_numpy(xf)
+        dist.all_reduce(xf_t)
+
+        # single-domain reference, computed by every rank for its own atoms
+        prep = g.workload.prepare(glob, ip, 0)
+        o = O.kernel_gpu_list(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
+        f_ref = np.zeros((glob.natoms, 3), dtype=np.float32)
+        prep.host.add_f(np.asarray(o["f"], dtype=np.float32), f_ref)
+        err = float(np.sqrt(((f_home[:dom.nhome] - f_ref[dom.home_ids]) ** 2).sum() / (f_ref[dom.home_ids] ** 2).sum()))
+        vir_ref = virial_from(np.concatenate([glob.x, np.zeros((glob.natoms, 1), np.float32)], 1), f_ref,
+                              prep.shift_vec, np.asarray(o["fshift"]))
+        vir_dd = -0.5 * (xf_t.numpy() + dom.shift_vec.astype(np.float64).T @ e[2:2 + 135].reshape(45, 3))
+        ret[rank] = dict(err=err, e_lj=e[0], e_el=e[1], e_lj_ref=o["Vvdw"], e_el_ref=o["Vc"],
+                         vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()),
+                         nhome=dom.nhome, nhalo=dom.nhalo, natoms=glob.natoms,
+                         nsci=(dom.pl_local.nsci, dom.pl_nonlocal.nsci))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,model,mcb", [(2, "spc", 0), (2, "spce", 200), (3, "spc", 0)])
+def test_slab_decomposition_matches_single_domain(world, model, mcb):
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, _free_port(), model, mcb, ret), nprocs=world, join=True)
+        res = [ret[r] for r in range(world)]
+    assert sum(r["nhome"] for r in res) == res[0]["natoms"]
+    for r in res:
+        assert r["nhalo"] > 0 and r["nsci"][1] > 0
+        # both sides are the double oracle on float32 coordinates; they differ by the float32 rounding
+        # of z + box_z for atoms imported across the periodic wrap (~1e-7 of a distance)
+        assert r["err"] < 2e-6, r
+        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
+        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r
+        assert r["vir_err"] < 1e-5, r

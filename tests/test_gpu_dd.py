@@ -1,0 +1,59 @@
+"""SlabRun (the bench.py --gpus N path) rehearsed on ONE GPU: two ranks share cuda:0 and talk
+over gloo (dd.py stages device tensors through the host for gloo; RCCL needs one GPU per
+rank).  Covers what the CPU test cannot: the HIP module's buffers aliased as torch tensors,
+local + non-local lists on two HIP streams, the resident per-step sequence."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_dd_cpu import _free_port  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, model, ret):
+    import gromacs_cosmo_amd as g
+    from gromacs_cosmo_amd import abi, dd
+    import oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
+        tiles = (2, 2, 2)
+        run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300)
+        dom = run.dom
+        # wreck the imported coordinates on the device: the step has to bring them back
+        run.xq_t[run.halo.halo_slots, :3] = 1e6
+        for _ in range(3):
+            run.step()
+        f_home = run.forces_home()
+        e = run.energies.cpu().numpy()
+        glob = g.system.water_box(tiles[0], tiles[1], tiles[2] * world, model=model)
+        prep = g.workload.prepare(glob, ip, 0)
+        o = O.kernel_gpu_list(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
+        f_ref = np.zeros((glob.natoms, 3), dtype=np.float32)
+        prep.host.add_f(np.asarray(o["f"], dtype=np.float32), f_ref)
+        fr = f_ref[dom.home_ids]
+        ret[rank] = dict(err=float(np.sqrt(((f_home - fr) ** 2).sum() / (fr ** 2).sum())),
+                         e_lj=float(e[0]), e_el=float(e[1]), e_lj_ref=float(o["Vvdw"]), e_el_ref=float(o["Vc"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["spc", "spce"])
+def test_slabrun_two_ranks_one_gpu(model):
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(2, _free_port(), model, ret), nprocs=2, join=True)
+        res = [ret[r] for r in range(2)]
+    for r in res:
+        assert r["err"] < 1e-5, r
+        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
+        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r

@@ -7,7 +7,7 @@ import gromacs_cosmo_amd as g
 from gromacs_cosmo_amd import abi
 import oracle as O
 
-variants = [int(v) for v in sys.argv[1:]] or [0]
+variants = [0]
 mcb = int(os.environ.get("MCB", "-1"))
 nb = g.gpu.NbnxnHip(0)
 if mcb < 0:

@@ -2,7 +2,7 @@
    hipcc ... -S --cuda-device-only nbnxn_kernel.hip -o k.s   usage: kisa.py k.s [name-substring ...]"""
 import sys, collections
 s = open(sys.argv[1]).read().split('\n')
-tags = sys.argv[2:] or ['kernel_v2ILi0ELb0ELb0ELb1E', 'kernel_v3ILi0ELb0ELb0ELb1E', 'nbnxn_kernelILi0ELb0ELb0ELb1E']
+tags = sys.argv[2:] or ['nbnxn_kernelILi0ELb0ELb0ELb1E', 'nbnxn_kernelILi1ELb1ELb0ELb1E']
 for tag in tags:
     st = [i for i, l in enumerate(s) if l.startswith('_Z') and tag in l and ':' in l]
     if not st:

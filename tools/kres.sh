@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel register / spill / occupancy table of nbnxn_kernel.hip (extra hipcc flags as arguments)
 cd "$(dirname "$0")/../gromacs-cosmo_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I../../include "$@" -c nbnxn_kernel.hip -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 |
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -I../../include "$@" -c nbnxn_kernel.hip -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 |
 python3 -c '
 import re,sys
 cur=None
@@ -9,7 +9,7 @@ for l in sys.stdin:
     m=re.search(r"Function Name: (\S+)",l)
     if m:
         n=m.group(1); k=re.search(r"nbnxn_kernel(_v\d)?ILi(\d)ELb(\d)ELb(\d)ELb(\d)",n)
-        cur=(k.group(1) or "_v1")+" el%s ener%s prune%s lds%s"%k.groups()[1:] if k else n[:40]; d={}
+        cur="k"+" el%s ener%s prune%s lds%s"%k.groups()[1:] if k else n[:40]; d={}
         continue
     for key in ("VGPRs:","VGPRs Spill:","Occupancy [waves/SIMD]:","LDS Size [bytes/block]:","ScratchSize [bytes/lane]:"):
         if key in l:
