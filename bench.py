@@ -88,10 +88,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    # rehearsal of the N > 1 path on a one-GPU box: BENCH_REHEARSAL=1 puts every rank on cuda:0 and
+    # uses gloo (RCCL needs one GPU per rank); its numbers mean nothing, it only proves the plumbing
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     tiles = tuple(int(t) for t in args.tiles.split(","))
     ener = not args.force_only
@@ -112,6 +120,7 @@ def main():
         assert nb.verify_pairlist(prep.pl) == 0
         natoms = system.natoms
         pair_slots = prep.pair_slots
+        roof_slots = prep.pair_slots
         # coordinates resident in HBM; this first call also prunes the fresh list
         f0, _ = nb.compute(prep.xq, flags)
 
@@ -131,12 +140,14 @@ def main():
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags)
         natoms = run.natoms_global
         pair_slots = run.pair_slots_local    # summed over ranks below
+        roof_slots = run.dom.pl_local.nci_tot * 64   # the timed kernel is this rank's LOCAL-list launch
         step = run.step          # step(ev) records ev around the local kernel
         stream = torch.cuda.ExternalStream(run.nb.stream(abi.LOCAL))
         sync = lambda: torch.cuda.synchronize()
         parallelism = f"dd{world} (z slabs, RCCL halo x/f)"
         cfg_extra = run.describe()
-        run.step()   # prunes
+        if args.mcb >= 0 or args.variant >= 0 or args.no_split:
+            raise SystemExit("--mcb/--variant/--no-split are single-GPU A/B switches")
 
     for _ in range(args.warmup):
         step()
@@ -165,25 +176,25 @@ def main():
     kernel_ms = max(kernel_ms_raw - event_pair_ms, 1e-6)
 
     if world > 1:
-        t = torch.tensor([wall, float(pair_slots), kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, float(pair_slots), kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         wall = float(tmax[0])
         pair_slots = float(tsum[1])
-        kernel_ms = float(tmax[2])
+        # kernel_ms stays rank 0's own: it is paired with rank 0's local-list pair count in the roofline
 
     if rank == 0:
         ms_per_step = 1e3 * wall / args.steps
         value = pair_slots * args.steps / wall
-        achieved_tflops = pair_slots / world * flops_pair / (kernel_ms * 1e-3) / 1e12
+        achieved_tflops = roof_slots * flops_pair / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "pair interactions/s (cluster pairs x 64 per step, nonbonded Verlet kernel)",
             "value": value, "unit": "pair/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, numbers meaningless)" if rehearsal else ""),
             "ns_per_day": 86400.0 * DT_FS * 1e-6 / (ms_per_step * 1e-3),
             "ns_per_day_note": f"nonbonded only, dt = {DT_FS} fs",
             "config": dict({"workload": f"{model.upper()} water {natoms} atoms ({'x'.join(map(str, tiles))} spc216 tiles"

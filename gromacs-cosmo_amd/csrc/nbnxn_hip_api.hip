@@ -532,7 +532,7 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     {
         nb->stream[1] = nb->stream[0];
     }
-    // event timing is off with two streams, as in the reference (nbnxn_cuda_data_mgmt.cu:626-627):
+    // event timing is off with two streams, as in the reference (nbnxn_cuda_data_mgmt.cu:714-715):
     // the events serialise the streams; on MI355X a pair also costs ~7 us of device time per launch
     nb->do_time = !nb->two_streams && (getenv("GMX_DISABLE_HIP_TIMING") == nullptr);
     for (int l = 0; l < 2; l++)

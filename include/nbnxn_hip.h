@@ -261,7 +261,7 @@ const char *nbnxn_hip_last_error(void);
 
 /* ------------------------------------------------------------------------------------
  * Device selection; replaces detect_cuda_gpus / init_gpu / free_gpu /
- * get_gpu_device_info_string (gmxlib/gpu_utils/gpu_utils.h:63-107).
+ * get_gpu_device_info_string (legacyheaders/gpu_utils.h:72-104).
  * ---------------------------------------------------------------------------------- */
 int nbnxn_hip_detect_gpus(int *ngpu, char *err_str, int err_len);
 int nbnxn_hip_init_gpu(int device_id, char *result_str, int result_len);
@@ -269,7 +269,7 @@ int nbnxn_hip_free_gpu(char *result_str, int result_len);
 int nbnxn_hip_get_current_gpu_device_id(void);
 int nbnxn_hip_get_gpu_device_info_string(char *s, int len, int device_id);
 
-/* pinned host memory; replaces pmalloc / pfree (gmxlib/cuda_tools/pmalloc_cuda.cu:45,91),
+/* pinned host memory; replaces pmalloc / pfree (legacyheaders/pmalloc_cuda.h:57,63),
  * the nbnxn_alloc_t / nbnxn_free_t hooks handed to nbnxn_init_pairlist_set and
  * nbnxn_atomdata_init (mdlib/forcerec.c:2247-2262). */
 void nbnxn_hip_pmalloc(void **h_ptr, size_t nbytes);
@@ -420,7 +420,7 @@ float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc);
 int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune);
 
 /* switches the module's HIP-event timing (wallclock_gpu_t accounting) on or off; the default
- * follows the reference's bDoTime (nbnxn_cuda_data_mgmt.cu:626-627): on with one stream unless
+ * follows the reference's bDoTime (nbnxn_cuda_data_mgmt.cu:714-715): on with one stream unless
  * GMX_DISABLE_HIP_TIMING is set, off with two.  Each timed launch carries two event records
  * (~7 us of device time on MI355X), so resident callers that launch every ~100 us turn it off. */
 int nbnxn_hip_set_timing(nbnxn_hip_ptr_t nb, int on);
