@@ -185,6 +185,15 @@ def main():
         pair_slots = float(tsum[1])
         # kernel_ms stays rank 0's own: it is paired with rank 0's local-list pair count in the roofline
 
+    # HBM bytes per launch of the timed kernel: PMC passes cannot run inside this process, so the
+    # figure measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command is kept
+    # under profiles/ and quoted only when the workload is the one it was measured on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_c_hbm_traffic.json")
+    if world == 1 and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
+            and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+
     if rank == 0:
         ms_per_step = 1e3 * wall / args.steps
         value = pair_slots * args.steps / wall
@@ -204,7 +213,8 @@ def main():
                             "parallelism": parallelism, "pair_slots_per_step": pair_slots,
                             "flops_per_pair": flops_pair}, **cfg_extra),
             "roofline": {"bound": "fp32-vector", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from profiles/r1_c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                          "kernel_ms": kernel_ms, "kernel_ms_events_raw": kernel_ms_raw, "event_pair_ms": event_pair_ms,
                          "note": "algorithmic flops = pair slots x nrnb.c cost (gmxlib/nrnb.c:101-106); duration = mean HIP-event time around the nonbonded kernel launch inside the timed region minus the latency of an empty event pair"},
         }
