@@ -116,7 +116,14 @@ struct nbnxn_hip {
     PList plist[2];
 
     // pinned staging for the small outputs (nb_staging, nbnxn_cuda_types.h:104-110)
-    float *fbase   = nullptr;   // one allocation: [out slots][f], so one memset clears both
+    float *fbase   = nullptr;   // one allocation: 2 x {[out slots][f]}, so one memset clears slots and forces
+    // In-kernel clear (nbnxn_hip_set_clear_in_kernel): the two halves of fbase alternate as the
+    // output buffer; every LOCAL launch zeroes the half that is NOT in use, and clear_outputs
+    // then only flips to it.  `cur` is the half in use, `clean` says the other half is all zero.
+    bool   clear_in_kernel = false;
+    int    cur             = 0;
+    bool   clean_other     = false;
+    size_t half_floats     = 0;      // floats per half: OUT_FLOATS + f.alloc
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
 
     nbx_wallclock_gpu_t timings;
@@ -188,11 +195,14 @@ int reserve_f(nbnxn_hip *nb, size_t n, bool *realloced)
     {
         if (nb->fbase) { HIP_TRY(hipFree(nb->fbase)); nb->fbase = nullptr; }
         const size_t na = n + n / 5 + 64;
-        HIP_TRY(hipMalloc((void **)&nb->fbase, (OUT_FLOATS + na) * sizeof(float)));
+        nb->half_floats = (OUT_FLOATS + na + 63) / 64 * 64;
+        HIP_TRY(hipMalloc((void **)&nb->fbase, 2 * nb->half_floats * sizeof(float)));
         HIP_TRY(hipMemsetAsync(nb->fbase, 0, OUT_FLOATS * sizeof(float), nb->stream[0]));
-        nb->out     = nb->fbase;
-        nb->f.p     = nb->fbase + OUT_FLOATS;
-        nb->f.alloc = na;
+        nb->cur         = 0;
+        nb->clean_other = false;
+        nb->out         = nb->fbase;
+        nb->f.p         = nb->fbase + OUT_FLOATS;
+        nb->f.alloc     = na;
         *realloced  = true;
     }
     nb->f.n = n;
@@ -301,6 +311,7 @@ int init_atomdata_impl(nbnxn_hip *nb, int natoms, int natoms_local, int ntype, c
     bool re = false;
     if (dev_reserve(nb->xq, natoms) || dev_reserve(nb->type, natoms) || reserve_f(nb, (size_t)natoms * 3, &re)) { return 1; }
     nb->natoms = natoms; nb->natoms_local = natoms_local;
+    nb->clean_other = false;   // the idle half was zeroed for the old atom count
     hipStream_t st = nb->stream[0];
     if (re && natoms > 0)
     {
@@ -349,6 +360,13 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     a.xq = nb->xq.p; a.f = nb->f.p; a.type = nb->type.p; a.shift_vec = nb->shift_vec; a.ntype = nb->ntype;
     a.nbfp = nb->nbfp.p;
     a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.out = nb->out;
+    a.zero = nullptr; a.zero_n4 = 0;
+    if (nb->clear_in_kernel && iloc == NBX_LOCAL)
+    {
+        // this launch also zeroes the idle half; clear_outputs will flip to it
+        a.zero    = reinterpret_cast<float4 *>(nb->fbase + (size_t)(1 - nb->cur) * nb->half_floats);
+        a.zero_n4 = (int)((OUT_FLOATS + (size_t)nb->natoms * 3 + 3) / 4);
+    }
     {
         // kernel-ready constants (nbnxn_kernel.h: nbx_kernel_k_t), rounded once from double
         const bool   ew = (nb->el_type != NBX_EL_RF);
@@ -375,6 +393,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, st));
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
     nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
+    if (a.zero) { nb->clean_other = true; }
     return 0;
 }
 
@@ -656,10 +675,20 @@ int nbnxn_hip_clear_outputs(nbnxn_hip_ptr_t nb, int flags)
 {
     if (check_handle(nb)) { return 1; }
     HIP_TRY(hipSetDevice(nb->device));
+    if (nb->clear_in_kernel && nb->clean_other)
+    {
+        // the last LOCAL launch left the idle half zeroed (stream order makes that visible to
+        // everything enqueued from here on): use it
+        nb->cur ^= 1;
+        nb->clean_other = false;
+        nb->out = nb->fbase + (size_t)nb->cur * nb->half_floats;
+        nb->f.p = nb->out + OUT_FLOATS;
+        return 0;
+    }
     if (flags & NBX_FORCE_VIRIAL)
     {
         // slots and forces are adjacent: one fill
-        HIP_TRY(hipMemsetAsync(nb->fbase, 0, (OUT_FLOATS + (size_t)nb->natoms * 3) * sizeof(float), nb->stream[0]));
+        HIP_TRY(hipMemsetAsync(nb->out, 0, (OUT_FLOATS + (size_t)nb->natoms * 3) * sizeof(float), nb->stream[0]));
     }
     else if (nb->natoms > 0) { HIP_TRY(hipMemsetAsync(nb->f.p, 0, (size_t)nb->natoms * 3 * sizeof(float), nb->stream[0])); }
     return 0;
@@ -874,6 +903,14 @@ int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)
 {
     if (check_handle(nb) || check_loc(iloc)) { return 1; }
     nb->plist[iloc].do_prune = do_prune != 0;
+    return 0;
+}
+
+int nbnxn_hip_set_clear_in_kernel(nbnxn_hip_ptr_t nb, int on)
+{
+    if (check_handle(nb)) { return 1; }
+    nb->clear_in_kernel = on != 0;
+    nb->clean_other     = false;
     return 0;
 }
 

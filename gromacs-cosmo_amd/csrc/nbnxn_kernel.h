@@ -53,6 +53,9 @@ struct nbx_kernel_args_t {
     const nbx_excl_t *excl;
     // accumulation slots [NBX_OUT_SLOTS][NBX_OUT_STRIDE]
     float *out;
+    // optional: zero_n4 float4s at `zero` are cleared by this launch (the idle output buffer)
+    float4 *zero;
+    int     zero_n4;
 };
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,

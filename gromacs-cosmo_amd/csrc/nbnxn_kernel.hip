@@ -32,11 +32,12 @@ namespace {
         const float *__restrict__ p_shift_vec, const float2 *__restrict__ p_nbfp,                   \
         const nbx_sci_t *__restrict__ p_sci, nbx_cj4_t *__restrict__ p_cj4,                         \
         const nbx_excl_t *__restrict__ p_excl, float *__restrict__ p_out, const int p_ntype,        \
-        const nbx_kernel_k_t p_k
+        float4 *__restrict__ p_zero, const int p_zero_n4, const nbx_kernel_k_t p_k
 #define NBX_KERNEL_ARGS_FROM_PARAMS                                                                \
     const nbx_kernel_view_t a = {p_xq, p_f, p_type, p_shift_vec, p_ntype, p_nbfp, p_sci, p_cj4, p_excl, p_out, p_k};
 #define NBX_KERNEL_CALL_ARGS(A)                                                                    \
-    (A).xq, (A).f, (A).type, (A).shift_vec, (A).nbfp, (A).sci, (A).cj4, (A).excl, (A).out, (A).ntype, (A).k
+    (A).xq, (A).f, (A).type, (A).shift_vec, (A).nbfp, (A).sci, (A).cj4, (A).excl, (A).out, (A).ntype, (A).zero,   \
+        (A).zero_n4, (A).k
 
 // device-side view with the same member names as nbx_kernel_args_t
 struct nbx_kernel_view_t {
@@ -364,6 +365,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     const int       sci   = e.sci;
     const int       ntype = a.ntype;
     const bool      central = (e.shift == NBX_CENTRAL);
+
+    // in-kernel clear of the idle output buffer (nbnxn_hip_set_clear_in_kernel): the next step
+    // accumulates into it, so no fill has to be dispatched between two steps
+    for (int i = blockIdx.x * 64 + lane; i < p_zero_n4; i += gridDim.x * 64) { p_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 
     nbx_jhdr_t  cur;
     nbx_jslot_t sa, sb;

@@ -69,6 +69,7 @@ def load():
     lib.nbnxn_hip_set_prune.argtypes = [vp, ci, ci]
     lib.nbnxn_hip_get_output_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
     lib.nbnxn_hip_set_timing.argtypes = [vp, ci]
+    lib.nbnxn_hip_set_clear_in_kernel.argtypes = [vp, ci]
     lib.nbnxn_hip_set_kernel_variant.argtypes = [vp, ci]
     # the host runtime raises instead of aborting the interpreter (gmx_fatal would abort)
     lib.nbnxn_hip_set_abort_on_error(0)
@@ -174,6 +175,9 @@ class NbnxnHip:
 
     def set_kernel_variant(self, v):
         self._chk(self.lib.nbnxn_hip_set_kernel_variant(self.h, v))
+
+    def set_clear_in_kernel(self, on):
+        self._chk(self.lib.nbnxn_hip_set_clear_in_kernel(self.h, int(on)))
 
     def set_timing(self, on):
         self._chk(self.lib.nbnxn_hip_set_timing(self.h, int(on)))

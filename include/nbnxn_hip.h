@@ -419,6 +419,14 @@ float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc);
  * the reference arms it in init_pairlist and disarms it in wait_gpu. */
 int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune);
 
+/* In-kernel clear (off by default).  When on, the module keeps two output buffers {energy
+ * slots, f}; every LOCAL launch also zeroes the one that is not in use and
+ * nbnxn_hip_clear_outputs just switches to it instead of dispatching a fill.  For resident
+ * callers that step every ~100 us, where the fill and its dispatch gap are ~7 % of the step.
+ * The addresses returned by get_device_buffers / get_output_slots change with every
+ * clear_outputs while this is on: query them after it. */
+int nbnxn_hip_set_clear_in_kernel(nbnxn_hip_ptr_t nb, int on);
+
 /* switches the module's HIP-event timing (wallclock_gpu_t accounting) on or off; the default
  * follows the reference's bDoTime (nbnxn_cuda_data_mgmt.cu:714-715): on with one stream unless
  * GMX_DISABLE_HIP_TIMING is set, off with two.  Each timed launch carries two event records

@@ -211,3 +211,29 @@ def test_many_atom_types_use_the_global_lj_table(nb):
     assert relrms(f, o["f"]) < FORCE_RTOL
     assert abs(e[0] - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"])
     assert abs(e[1] - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"])
+
+
+def test_clear_in_kernel_matches_fill(nb):
+    """nbnxn_hip_set_clear_in_kernel: ping-pong output buffers zeroed by the previous launch give
+    the same forces and energies as a dispatched fill, step after step, also when a force-only
+    step sits between two energy steps."""
+    p, ip, d = load_small("spce3240_ewald09")
+    _upload(nb, p, ip)
+    f_ref, e_ref = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    nb.set_clear_in_kernel(True)
+    try:
+        for flags in (abi.FORCE_VIRIAL, 0, abi.FORCE_VIRIAL, abi.FORCE_VIRIAL):
+            nb.clear_outputs(flags)
+            nb.launch_kernel_resident(flags)
+            f = np.zeros_like(f_ref)
+            nb.launch_cpyback(f, flags)
+            nb.wait_gpu(flags)
+            assert relrms(f, f_ref) < 2e-6
+            if flags:
+                elj, eel, fsh = nb.read_outputs()
+                assert abs(elj - e_ref[0]) < 1e-6 * abs(e_ref[0]) and abs(eel - e_ref[1]) < 1e-6 * abs(e_ref[1])
+                assert np.abs(fsh - e_ref[2]).max() < 1e-5 * np.abs(e_ref[2]).max()
+    finally:
+        nb.set_clear_in_kernel(False)
+    f2, e2 = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert relrms(f2, f_ref) < 2e-6 and abs(e2[1] - e_ref[1]) < 1e-6 * abs(e_ref[1])
