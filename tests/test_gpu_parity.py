@@ -237,3 +237,32 @@ def test_clear_in_kernel_matches_fill(nb):
         nb.set_clear_in_kernel(False)
     f2, e2 = nb.compute(p.xq, abi.FORCE_VIRIAL)
     assert relrms(f2, f_ref) < 2e-6 and abs(e2[1] - e_ref[1]) < 1e-6 * abs(e_ref[1])
+
+
+@pytest.mark.parametrize("model", ["spc", "spce"])
+def test_config4_size_properties(nb, model):
+    """BASELINE config 4 size (13x13x14 tiles, 1,533,168 atoms, >1e9 pair slots) on one GPU.  The
+    full oracle cannot run that in seconds, so: (1) a sample of atoms against brute force over ALL
+    atoms in double; (2) the box is a periodic tiling of spc216, so the energies are 13*13*14/8
+    times those the oracle finds for the 2x2x2 tiling (forces are not compared tile-to-tile: the
+    float32 rounding of coordinates near 26 nm moves them by ~2e-5); (3) Newton's third law."""
+    from util import brute_force_sample
+    ip = g.system.reaction_field(1.0) if model == "spc" else g.system.ewald(1.0)
+    small = g.system.water_box(2, 2, 2, model=model)
+    ps = g.workload.prepare(small, ip, 0)
+    o = O.kernel_gpu_list(ps.xq, ps.type, ps.ntype, ps.nbfp, ps.shift_vec, ps.pl, ip)
+    tiles = (13, 13, 14)
+    ntile = tiles[0] * tiles[1] * tiles[2]
+    big = g.system.water_box(*tiles, model=model)
+    p = g.workload.prepare(big, ip, nb.min_ci_balanced())
+    assert p.pl.nci_tot * 64 > 1.0e9
+    _upload(nb, p, ip)
+    assert nb.verify_pairlist(p.pl) == 0
+    fnb, (elj, eel, fsh) = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    f = np.zeros((big.natoms, 3), dtype=np.float32)
+    p.host.add_f(fnb, f)
+    idx = np.random.default_rng(4).choice(big.natoms, 96, replace=False)
+    assert relrms(f[idx], brute_force_sample(big, ip, idx)) < FORCE_RTOL
+    assert abs(elj - o["Vvdw"] * ntile / 8) < ENERGY_RTOL * abs(o["Vvdw"] * ntile / 8)
+    assert abs(eel - o["Vc"] * ntile / 8) < ENERGY_RTOL * abs(o["Vc"] * ntile / 8)
+    assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-3 * np.abs(f).max()

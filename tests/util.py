@@ -55,3 +55,35 @@ def virial_from(xq, f, shift_vec, fshift):
     v = -0.5 * (x.T @ np.asarray(f, dtype=np.float64))
     v += -0.5 * (shift_vec.astype(np.float64).T @ np.asarray(fshift, dtype=np.float64))
     return v
+
+
+def brute_force_sample(system, ip, idx):
+    """Forces on the atoms `idx` of a water System in double, from ALL atoms by minimum image: the
+    list-independent truth for a sample of a box too large for the full oracle (pair arithmetic
+    of nbnxn_kernel_ref_inner.h:117-372 with analytical Ewald; molecules of 3 atoms excluded)."""
+    from scipy.special import erf
+    x = system.x.astype(np.float64)
+    box = system.box.astype(np.float64)
+    q = system.q.astype(np.float64)
+    out = np.zeros((len(idx), 3))
+    rc2 = ip.rcoulomb ** 2
+    for n, i in enumerate(idx):
+        d = x[i] - x
+        d -= box * np.floor(d / box + 0.5)
+        r2 = (d * d).sum(1)
+        near = np.nonzero(r2 < rc2)[0]
+        near = near[near != i]
+        d, r2 = d[near], r2[near]
+        bit = (near // 3 != i // 3).astype(np.float64)
+        r = np.sqrt(r2)
+        qq = ip.epsfac * q[i] * q[near]
+        c6 = 6.0 * system.c6[system.type[i], system.type[near]]
+        c12 = 12.0 * system.c12[system.type[i], system.type[near]]
+        fs = bit * (c12 / r2 ** 6 - c6 / r2 ** 3) / r2
+        if ip.el_type == abi.EL_RF:
+            fs += qq * (bit / (r2 * r) - 2.0 * ip.k_rf)
+        else:
+            b = ip.ewaldcoeff_q
+            fs += qq * (bit / (r2 * r) - (erf(b * r) / r - 2.0 * b / np.sqrt(np.pi) * np.exp(-b * b * r2)) / r2)
+        out[n] = (fs[:, None] * d).sum(0)
+    return out
