@@ -266,3 +266,28 @@ def test_config4_size_properties(nb, model):
     assert abs(elj - o["Vvdw"] * ntile / 8) < ENERGY_RTOL * abs(o["Vvdw"] * ntile / 8)
     assert abs(eel - o["Vc"] * ntile / 8) < ENERGY_RTOL * abs(o["Vc"] * ntile / 8)
     assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-3 * np.abs(f).max()
+
+
+def test_config5_size_properties(nb):
+    """BASELINE config 5 size on one GPU: 3,000,000 atoms of the 8-type, exclusion-dense chain
+    mixture (no reference fixture exists for it), analytical Ewald.  A sample of atoms
+    against brute force over all atoms in double, Newton's third law, and the virial from the
+    kernel's shift forces against the pair virial of the sample's forces is left to the small
+    fixtures; here the point is size: 3.0e6 atoms, 1.7e9 pair slots, 5.9e5 exclusion words."""
+    from util import brute_force_sample
+    ip = g.system.ewald(1.0)
+    big = g.system.lj_chain_mixture(3000000)
+    p = g.workload.prepare(big, ip, nb.min_ci_balanced())
+    assert p.pl.nci_tot * 64 > 1.5e9
+    _upload(nb, p, ip)
+    assert nb.verify_pairlist(p.pl) == 0
+    fnb, (elj, eel, fsh) = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    f = np.zeros((big.natoms, 3), dtype=np.float32)
+    p.host.add_f(fnb, f)
+    idx = np.random.default_rng(5).choice(big.natoms, 64, replace=False)
+    assert relrms(f[idx], brute_force_sample(big, ip, idx)) < FORCE_RTOL
+    assert np.isfinite(elj) and np.isfinite(eel)
+    assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-3 * np.abs(f).max()
+    # the pruned list gives the same forces on the next step
+    f2, _ = nb.compute(p.xq, 0)
+    assert relrms(f2, fnb) < 2e-6

@@ -58,9 +58,9 @@ def virial_from(xq, f, shift_vec, fshift):
 
 
 def brute_force_sample(system, ip, idx):
-    """Forces on the atoms `idx` of a water System in double, from ALL atoms by minimum image: the
+    """Forces on the atoms `idx` of a System in double, from ALL atoms by minimum image: the
     list-independent truth for a sample of a box too large for the full oracle (pair arithmetic
-    of nbnxn_kernel_ref_inner.h:117-372 with analytical Ewald; molecules of 3 atoms excluded)."""
+    of nbnxn_kernel_ref_inner.h:117-372 with analytical Ewald; exclusions from the topology CSR)."""
     from scipy.special import erf
     x = system.x.astype(np.float64)
     box = system.box.astype(np.float64)
@@ -74,7 +74,7 @@ def brute_force_sample(system, ip, idx):
         near = np.nonzero(r2 < rc2)[0]
         near = near[near != i]
         d, r2 = d[near], r2[near]
-        bit = (near // 3 != i // 3).astype(np.float64)
+        bit = (~np.isin(near, system.excl_a[system.excl_index[i]:system.excl_index[i + 1]])).astype(np.float64)
         r = np.sqrt(r2)
         qq = ip.epsfac * q[i] * q[near]
         c6 = 6.0 * system.c6[system.type[i], system.type[near]]
