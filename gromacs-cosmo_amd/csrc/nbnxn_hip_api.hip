@@ -124,6 +124,12 @@ struct nbnxn_hip {
     int    cur             = 0;
     bool   clean_other     = false;
     size_t half_floats     = 0;      // floats per half: OUT_FLOATS + f.alloc
+    // device-side atom-data moves (nbnxn_hip_set_atom_order / copy_x_to_xq / add_f)
+    DevBuf<int>   d_a, d_cell;      // grid slot -> caller atom (-1: filler); caller atom -> grid slot
+    DevBuf<float> d_x, d_fa;        // staging for a host x / host f in caller order
+    float        *h_fa = nullptr;   // pinned landing area of d_fa
+    size_t        h_fa_alloc = 0;
+    int           natoms_real = 0;
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
 
     nbx_wallclock_gpu_t timings;
@@ -312,6 +318,7 @@ int init_atomdata_impl(nbnxn_hip *nb, int natoms, int natoms_local, int ntype, c
     if (dev_reserve(nb->xq, natoms) || dev_reserve(nb->type, natoms) || reserve_f(nb, (size_t)natoms * 3, &re)) { return 1; }
     nb->natoms = natoms; nb->natoms_local = natoms_local;
     nb->clean_other = false;   // the idle half was zeroed for the old atom count
+    nb->d_a.n = 0; nb->d_cell.n = 0;   // a new grid: the atom order has to be set again
     hipStream_t st = nb->stream[0];
     if (re && natoms > 0)
     {
@@ -709,6 +716,8 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     }
     (void)hipFree(nb->shift_vec);
     (void)hipHostFree(nb->h_stage);
+    dev_free(nb->d_a); dev_free(nb->d_cell); dev_free(nb->d_x); dev_free(nb->d_fa);
+    if (nb->h_fa) { (void)hipHostFree(nb->h_fa); }
     if (nb->two_streams)
     {
         (void)hipEventDestroy(nb->misc_ops_done); (void)hipEventDestroy(nb->nonlocal_done);
@@ -897,6 +906,100 @@ float nbnxn_hip_last_kernel_ms(nbnxn_hip_ptr_t nb, int iloc)
     if (!nb || iloc < 0 || iloc > 1 || !nb->do_time || !nb->k_timed[iloc]) { return -1.0f; }
     if (hipEventSynchronize(nb->k_stop[iloc]) != hipSuccess) { return -1.0f; }
     return elapsed(nb->k_start[iloc], nb->k_stop[iloc]);
+}
+
+/* ---- device-side atom-data moves ---- */
+
+int nbnxn_hip_set_atom_order(nbnxn_hip_ptr_t nb, int natoms_real, const int *a, const int *cell)
+{
+    if (check_handle(nb)) { return 1; }
+    if (nb->natoms <= 0) { return nbx_fail("set_atom_order before init_atomdata"); }
+    if (!a || !cell || natoms_real < 0 || natoms_real > nb->natoms) { return nbx_fail("bad atom order arguments"); }
+    // the two index arrays must be inverse permutations of each other (nbs->a / nbs->cell)
+    int nreal = 0;
+    for (int s = 0; s < nb->natoms; s++)
+    {
+        if (a[s] < -1 || a[s] >= natoms_real) { return nbx_fail("grid slot %d holds atom %d outside [-1,%d)", s, a[s], natoms_real); }
+        if (a[s] >= 0) { nreal++; if (cell[a[s]] != s) { return nbx_fail("cell[a[%d]] = %d is not %d", s, cell[a[s]], s); } }
+    }
+    if (nreal != natoms_real) { return nbx_fail("%d grid slots hold atoms, expected %d", nreal, natoms_real); }
+    HIP_TRY(hipSetDevice(nb->device));
+    if (dev_reserve(nb->d_a, nb->natoms) || dev_reserve(nb->d_cell, natoms_real) ||
+        dev_reserve(nb->d_x, (size_t)natoms_real * 3) || dev_reserve(nb->d_fa, (size_t)natoms_real * 3)) { return 1; }
+    if ((size_t)natoms_real * 3 > nb->h_fa_alloc)
+    {
+        if (nb->h_fa) { HIP_TRY(hipHostFree(nb->h_fa)); nb->h_fa = nullptr; }
+        nb->h_fa_alloc = (size_t)natoms_real * 3 + (size_t)natoms_real * 3 / 5 + 64;
+        HIP_TRY(hipHostMalloc((void **)&nb->h_fa, nb->h_fa_alloc * sizeof(float), hipHostMallocDefault));
+    }
+    hipStream_t st = nb->stream[0];
+    HIP_TRY(hipMemcpyAsync(nb->d_a.p, a, (size_t)nb->natoms * sizeof(int), hipMemcpyHostToDevice, st));
+    if (natoms_real > 0) { HIP_TRY(hipMemcpyAsync(nb->d_cell.p, cell, (size_t)natoms_real * sizeof(int), hipMemcpyHostToDevice, st)); }
+    HIP_TRY(hipStreamSynchronize(st));
+    nb->natoms_real = natoms_real;
+    return 0;
+}
+
+int nbnxn_hip_upload_xq_flat(nbnxn_hip_ptr_t nb, const float *xq, int iloc)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    if (!xq) { return nbx_fail("null xq"); }
+    int begin, len;
+    loc_range(nb, iloc, &begin, &len);
+    HIP_TRY(hipSetDevice(nb->device));
+    if (len > 0)
+    {
+        HIP_TRY(hipMemcpyAsync(nb->xq.p + begin, xq + (size_t)begin * 4, (size_t)len * sizeof(float4), hipMemcpyHostToDevice, nb->stream[iloc]));
+    }
+    return 0;
+}
+
+int nbnxn_hip_copy_x_to_xq(nbnxn_hip_ptr_t nb, const float *x, int x_on_device, int iloc)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    if (nb->d_a.n == 0 || (int)nb->d_a.n != nb->natoms) { return nbx_fail("copy_x_to_xq before set_atom_order (or after a new init_atomdata)"); }
+    if (!x) { return nbx_fail("null x"); }
+    int begin, len;
+    loc_range(nb, iloc, &begin, &len);
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t  st = nb->stream[iloc];
+    const float *dx = x;
+    if (!x_on_device)
+    {
+        // the whole caller-order array goes up on the LOCAL call; the non-local call reuses it
+        if (iloc == NBX_LOCAL || !nb->two_streams)
+        {
+            HIP_TRY(hipMemcpyAsync(nb->d_x.p, x, (size_t)nb->natoms_real * 3 * sizeof(float), hipMemcpyHostToDevice, st));
+            if (nb->two_streams) { HIP_TRY(hipEventRecord(nb->misc_ops_done, st)); }
+        }
+        else { HIP_TRY(hipStreamWaitEvent(st, nb->misc_ops_done, 0)); }
+        dx = nb->d_x.p;
+    }
+    HIP_TRY(nbx_launch_gather_x(nb->d_a.p, dx, nb->xq.p, begin, len, st));
+    return 0;
+}
+
+int nbnxn_hip_add_f(nbnxn_hip_ptr_t nb, float *f, int f_on_device, int a0, int n, int aloc)
+{
+    if (check_handle(nb) || check_loc(aloc)) { return 1; }
+    if (nb->d_cell.n == 0 || (int)nb->d_a.n != nb->natoms) { return nbx_fail("add_f before set_atom_order (or after a new init_atomdata)"); }
+    if (!f || a0 < 0 || n < 0 || a0 + n > nb->natoms_real) { return nbx_fail("add_f: atom range [%d,%d) outside [0,%d)", a0, a0 + n, nb->natoms_real); }
+    if (n == 0) { return 0; }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = nb->stream[aloc];
+    if (f_on_device)
+    {
+        HIP_TRY(nbx_launch_scatter_f(nb->d_cell.p, nb->f.p, f, a0, n, true, st));
+        return 0;
+    }
+    // host f: permute on the device, bring the dense block down, add on the host (blocking, like
+    // the reference's host loop)
+    HIP_TRY(nbx_launch_scatter_f(nb->d_cell.p, nb->f.p, nb->d_fa.p, a0, n, false, st));
+    HIP_TRY(hipMemcpyAsync(nb->h_fa, nb->d_fa.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float *o = f + (size_t)a0 * 3;
+    for (size_t i = 0; i < (size_t)n * 3; i++) { o[i] += nb->h_fa[i]; }
+    return 0;
 }
 
 int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)

@@ -61,4 +61,8 @@ struct nbx_kernel_args_t {
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
                                 hipStream_t stream);
 
+// nbnxn_atomdata.hip
+hipError_t nbx_launch_gather_x(const int *a, const float *x, float4 *xq, int begin, int n, hipStream_t stream);
+hipError_t nbx_launch_scatter_f(const int *cell, const float *fnb, float *f, int a0, int n, bool add, hipStream_t stream);
+
 #endif

@@ -7,6 +7,7 @@ every entry point raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -19,6 +20,25 @@ class HipError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64 (rpath $ORIGIN).  Two HIP
+    runtimes in one process do not both see the GPU, and which one gets loaded depends on whether
+    torch or this library came first.  When a torch with a bundled runtime is installed, load THAT
+    copy first (without importing torch), so that libnbnxn_hip.so and a later `import torch` share it."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -26,6 +46,7 @@ def load():
     path = os.environ.get("NBNXN_HIP_LIB") or os.path.join(abi.lib_dir(), "libnbnxn_hip.so")   # override: kernel A/B builds
     if not os.path.exists(path):
         raise HipError(f"{path} is missing: the HIP extension was not built (python -c 'import __graft_entry__ as g; g.build()')")
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.nbnxn_hip_last_error.restype = C.c_char_p
@@ -67,6 +88,10 @@ def load():
     lib.nbnxn_hip_last_kernel_ms.argtypes = [vp, ci]
     lib.nbnxn_hip_last_kernel_ms.restype = cf
     lib.nbnxn_hip_set_prune.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_set_atom_order.argtypes = [vp, ci, vp, vp]
+    lib.nbnxn_hip_upload_xq_flat.argtypes = [vp, vp, ci]
+    lib.nbnxn_hip_copy_x_to_xq.argtypes = [vp, vp, ci, ci]
+    lib.nbnxn_hip_add_f.argtypes = [vp, vp, ci, ci, ci, ci]
     lib.nbnxn_hip_get_output_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
     lib.nbnxn_hip_set_timing.argtypes = [vp, ci]
     lib.nbnxn_hip_set_clear_in_kernel.argtypes = [vp, ci]
@@ -175,6 +200,37 @@ class NbnxnHip:
 
     def set_kernel_variant(self, v):
         self._chk(self.lib.nbnxn_hip_set_kernel_variant(self.h, v))
+
+    # ---- device-side atom-data moves (nbnxn_atomdata.c:1141, :1600) ----
+    def set_atom_order(self, natoms_real, a, cell):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        cell = np.ascontiguousarray(cell, dtype=np.int32)
+        assert len(a) == self.natoms and len(cell) == natoms_real
+        self._chk(self.lib.nbnxn_hip_set_atom_order(self.h, natoms_real, abi.ptr(a), abi.ptr(cell)))
+        self.natoms_real = natoms_real
+
+    def upload_xq(self, xq, iloc=abi.LOCAL):
+        assert xq.dtype == np.float32 and xq.shape == (self.natoms, 4) and xq.flags.c_contiguous
+        self._keep["xq"] = xq
+        self._chk(self.lib.nbnxn_hip_upload_xq_flat(self.h, abi.ptr(xq), iloc))
+
+    def copy_x_to_xq(self, x, iloc=abi.LOCAL):
+        """x: numpy [natoms_real, 3] float32 (host) or an int device address."""
+        if isinstance(x, int):
+            self._chk(self.lib.nbnxn_hip_copy_x_to_xq(self.h, C.c_void_p(x), 1, iloc))
+        else:
+            assert x.dtype == np.float32 and x.shape == (self.natoms_real, 3) and x.flags.c_contiguous
+            self._keep["x"] = x
+            self._chk(self.lib.nbnxn_hip_copy_x_to_xq(self.h, abi.ptr(x), 0, iloc))
+
+    def add_f(self, f, a0=0, n=None, aloc=abi.LOCAL):
+        """f: numpy [natoms_real, 3] float32 (host, updated on return) or an int device address."""
+        n = self.natoms_real - a0 if n is None else n
+        if isinstance(f, int):
+            self._chk(self.lib.nbnxn_hip_add_f(self.h, C.c_void_p(f), 1, a0, n, aloc))
+        else:
+            assert f.dtype == np.float32 and f.shape == (self.natoms_real, 3) and f.flags.c_contiguous
+            self._chk(self.lib.nbnxn_hip_add_f(self.h, abi.ptr(f), 0, a0, n, aloc))
 
     def set_clear_in_kernel(self, on):
         self._chk(self.lib.nbnxn_hip_set_clear_in_kernel(self.h, int(on)))

@@ -408,6 +408,31 @@ int nbnxn_hip_verify_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc,
                                    int ncj4, const nbx_cj4_t *cj4,
                                    int nexcl, const nbx_excl_t *excl);
 
+/* ------------------------------------------------------------------------------------
+ * Device-side atom-data moves.  The reference permutes coordinates into grid
+ * order and forces back into caller order on the host every step
+ * (nbnxn_atomdata_copy_x_to_nbat_x, mdlib/nbnxn_atomdata.c:1141; nbnxn_atomdata_add_nbat_f_to_f,
+ * :1600).  Here the two index arrays of the search (nbs->a and nbs->cell,
+ * nbnxn_search.c:1588-1660) are uploaded once per search and both permutations run on the GPU,
+ * so a caller moves 12 B per atom each way instead of the padded 16 B + 12 B, or nothing at
+ * all when its x and f live in HBM.
+ * ---------------------------------------------------------------------------------- */
+
+/* a[natoms padded, as given to init_atomdata]: grid slot -> caller atom, -1 for fillers;
+ * cell[natoms_real]: caller atom -> grid slot.  Call after init_atomdata of every search. */
+int nbnxn_hip_set_atom_order(nbnxn_hip_ptr_t nb, int natoms_real, const int *a, const int *cell);
+
+/* uploads a whole host xq range (charges and filler positions change only with the search) */
+int nbnxn_hip_upload_xq_flat(nbnxn_hip_ptr_t nb, const float *xq, int iloc);
+
+/* nbnxn_atomdata_copy_x_to_nbat_x: x [natoms_real*3] in caller order (host memory, or device
+ * memory when x_on_device) -> the xyz of the atom slots of locality iloc; async on its stream. */
+int nbnxn_hip_copy_x_to_xq(nbnxn_hip_ptr_t nb, const float *x, int x_on_device, int iloc);
+
+/* nbnxn_atomdata_add_nbat_f_to_f: f[at] += fnb[cell[at]] for at in [a0, a0+n).  Device f: async
+ * on the stream of aloc.  Host f: returns when f is updated. */
+int nbnxn_hip_add_f(nbnxn_hip_ptr_t nb, float *f, int f_on_device, int a0, int n, int aloc);
+
 /* reads the (possibly pruned) cj4 array back from HBM; for tests of the prune flavour. */
 int nbnxn_hip_download_cj4(nbnxn_hip_ptr_t nb, int iloc, int ncj4, nbx_cj4_t *cj4);
 

@@ -291,3 +291,61 @@ def test_config5_size_properties(nb):
     # the pruned list gives the same forces on the next step
     f2, _ = nb.compute(p.xq, 0)
     assert relrms(f2, fnb) < 2e-6
+
+
+def test_device_atomdata_moves_match_host_library(nb):
+    """nbnxn_atomdata_copy_x_to_nbat_x / add_nbat_f_to_f on the device against the
+    host library's versions, bit for bit (they are permutations plus one add), for host and
+    device-resident x / f, on the 97,200-atom box."""
+    import torch
+    from gromacs_cosmo_amd.dd import _DevArray
+    s = g.system.water_box(5, 5, 6, model="spce")
+    ip = g.system.ewald(1.0)
+    p = g.workload.prepare(s, ip, nb.min_ci_balanced())
+    _upload(nb, p, ip)
+    nb.set_atom_order(s.natoms, p.host.atom_order(), p.host.cell_index())
+    rng = np.random.default_rng(11)
+    x2 = (s.x + rng.normal(0, 0.002, s.x.shape)).astype(np.float32)
+    xq_ref = p.xq.copy()
+    p.host.copy_x_to_xq(x2, xq_ref)
+    d_xq, d_f, _ = nb.device_buffers()
+    xq_t = torch.as_tensor(_DevArray(d_xq, (p.natoms, 4)), device="cuda:0")
+    # host x
+    nb.upload_xq(p.xq)
+    nb.copy_x_to_xq(x2)
+    nb.wait_gpu(0)
+    torch.cuda.synchronize()
+    assert np.array_equal(xq_t.cpu().numpy(), xq_ref)
+    # device x
+    nb.upload_xq(p.xq)
+    x_t = torch.from_numpy(x2).cuda()
+    torch.cuda.synchronize()
+    nb.copy_x_to_xq(x_t.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(xq_t.cpu().numpy(), xq_ref)
+    # a step on the moved coordinates, then forces back into caller order three ways
+    nb.clear_outputs(0)
+    nb.launch_kernel_resident(0)
+    fnb = np.zeros((p.natoms, 3), dtype=np.float32)
+    nb.launch_cpyback(fnb, 0)
+    nb.wait_gpu(0)
+    f0 = rng.normal(0, 100, s.x.shape).astype(np.float32)
+    f_ref = f0.copy()
+    p.host.add_f(fnb, f_ref)
+    f_host = f0.copy()
+    nb.add_f(f_host)
+    assert np.array_equal(f_host, f_ref)
+    f_t = torch.from_numpy(f0).cuda()
+    torch.cuda.synchronize()
+    nb.add_f(f_t.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(f_t.cpu().numpy(), f_ref)
+    # a sub-range, as the reference calls it per locality
+    f_part = f0.copy()
+    nb.add_f(f_part, a0=1000, n=5000)
+    assert np.array_equal(f_part[1000:6000], f_ref[1000:6000]) and np.array_equal(f_part[:1000], f0[:1000])
+    # and the forces are those of the oracle on the moved coordinates
+    o = O.kernel_gpu_list(xq_ref, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    assert relrms(fnb, o["f"]) < FORCE_RTOL
+    with pytest.raises(g.gpu.HipError):
+        nb.add_f(f_part, a0=s.natoms - 10, n=20)
