@@ -164,9 +164,12 @@ int set_params(nbnxn_hip *nb, int el_type, float rcoulomb, float rvdw, float rli
 {
     if (el_type != NBX_EL_RF && el_type != NBX_EL_EWALD_ANA) { return nbx_fail("unsupported electrostatics flavour %d", el_type); }
     if (!(rcoulomb > 0)) { return nbx_fail("rcoulomb must be > 0"); }
-    if (rvdw != rcoulomb)
+    // twin-range: only rvdw < rcoulomb with Ewald (what PME load balancing produces and the only
+    // combination the Verlet scheme allows, readir.c / nbnxn_cuda_data_mgmt.cu:303-357)
+    if (rvdw > rcoulomb || !(rvdw > 0)) { return nbx_fail("rvdw (%g) must be in (0, rcoulomb = %g]", rvdw, rcoulomb); }
+    if (rvdw != rcoulomb && el_type == NBX_EL_RF)
     {
-        return nbx_fail("rvdw (%g) != rcoulomb (%g): the twin-range (VDW_CUTOFF_CHECK) flavours are not built yet", rvdw, rcoulomb);
+        return nbx_fail("rvdw (%g) != rcoulomb (%g) with reaction field: the Verlet scheme has no such flavour", rvdw, rcoulomb);
     }
     if (el_type == NBX_EL_EWALD_ANA && beta * beta * rcoulomb * rcoulomb > 16.0f)
     {
@@ -385,6 +388,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
         a.k.escale   = (float)(1.0 / b);
         a.k.rc2      = (float)(b * b * (double)nb->rcoulomb * (double)nb->rcoulomb);
         a.k.rlist2   = (float)(b * b * (double)pl.rlist * (double)pl.rlist);
+        a.k.rvdw2    = (float)(b * b * (double)nb->rvdw * (double)nb->rvdw);
         a.k.sh       = (float)((double)nb->sh_ewald / b);
         a.k.rep12    = (float)((double)nb->rep_cpot / 12.0 / std::pow(b, 12));
         a.k.ndisp6   = (float)(-(double)nb->disp_cpot / 6.0 / std::pow(b, 6));
@@ -397,7 +401,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     }
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
-    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, st));
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->rvdw < nb->rcoulomb, st));
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
     nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
     if (a.zero) { nb->clean_other = true; }

@@ -27,6 +27,7 @@ struct nbx_kernel_k_t {
     float c12scale;    // beta^13 | 1
     float escale;      // 1/beta | 1: multiplies the accumulated energies at the end
     float rc2, rlist2; // scaled cut-off and list radius, squared
+    float rvdw2;       // scaled LJ cut-off squared (twin-range flavour)
     float sh;          // sh_ewald / beta
     float rep12;       // rep_cpot / 12, scaled by beta^-12 for Ewald
     float ndisp6;      // -disp_cpot / 6, scaled by beta^-6 for Ewald
@@ -58,7 +59,7 @@ struct nbx_kernel_args_t {
     int     zero_n4;
 };
 
-hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
+hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune, bool vdw_cutoff,
                                 hipStream_t stream);
 
 // nbnxn_atomdata.hip

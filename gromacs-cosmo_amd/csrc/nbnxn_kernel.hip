@@ -205,7 +205,7 @@ __device__ __forceinline__ float and_mask(const float v, const int m)
     return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
 }
 
-template <int EL, bool ENER, bool PRUNE>
+template <int EL, bool ENER, bool PRUNE, bool VDWC>
 __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
                                         const float2 c, const unsigned wexcl, const int bitpos, const bool allowed,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
@@ -221,7 +221,10 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     const float inv_r2 = inv_r * inv_r;
     const float inv_r6 = inv_r2 * inv_r2 * inv_r2;
     // (F_lj + F_coulomb) * r^2, as r^-6 (c12 r^-6 - c6) + qq / r
-    const float lj6 = inv_r6 * fmaf(c.y, inv_r6, -c.x);
+    float lj6 = inv_r6 * fmaf(c.y, inv_r6, -c.x);
+    // twin-range flavour (VDW_CUTOFF_CHECK, nbnxn_cuda_kernel.cuh:405-409, 436-441): rvdw < rcoulomb
+    const bool vdw_in_range = VDWC ? (r2 < a.k.rvdw2) : true;
+    if (VDWC) { lj6 = vdw_in_range ? lj6 : 0.0f; }
     const float qq  = xi.w * xj.w;
     // LJ + plain Coulomb vanish for excluded pairs; the reaction-field / Ewald correction stays
     const float t = and_mask(fmaf(qq, inv_r, lj6) * inv_r2, m);
@@ -240,7 +243,8 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     {
         // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6 = c12 r^-12 - c6 r^-6
         const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
-        const float elj   = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
+        float       elj   = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
+        if (VDWC) { elj = vdw_in_range ? elj : 0.0f; }
         float       eel;
         if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf)); }
         else { eel = qq * (and_mask(inv_r - a.k.sh, m) - gv); }
@@ -284,7 +288,7 @@ __device__ __forceinline__ void load_jslot(const nbx_kernel_view_t &a, int cj, i
     s.t = a.type[cj * 8 + tidxj];
 }
 
-template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS, int JM>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, bool NBFP_LDS, int JM>
 __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
                                             const unsigned thi, float (&fix)[8], float (&fiy)[8], float (&fiz)[8],
                                             const nbx_jslot_t &s, const int cj, const unsigned wexcl,
@@ -327,7 +331,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_interaction<EL, ENER, PRUNE>(a, xi[i], xj, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
+            pair_interaction<EL, ENER, PRUNE, VDWC>(a, xi[i], xj, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
@@ -343,7 +347,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
 #define NBX_KERNEL_WAVES 4
 #endif
 
-template <int EL, bool ENER, bool PRUNE, bool NBFP_LDS>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, bool NBFP_LDS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KERNEL_WAVES, 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
 {
     NBX_KERNEL_ARGS_FROM_PARAMS
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     }
 
 #define NBX_JCLUSTER(JM, SLOT)                                                                             \
-    jcluster<EL, ENER, PRUNE, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
+    jcluster<EL, ENER, PRUNE, VDWC, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
                                                nfj, E_lj, E_el, ox, oy, oz)
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
@@ -529,26 +533,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     }
 }
 
-template <int EL, bool ENER, bool PRUNE>
+template <int EL, bool ENER, bool PRUNE, bool VDWC>
 void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
 {
-    if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-    else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
 }
 
 } // namespace
 
-hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune,
+hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune, bool vdw_cutoff,
                                 hipStream_t stream)
 {
     if (nsci <= 0) { return hipSuccess; }
-#define NBX_DISPATCH(EL)                                                                     \
-    if (ener) { if (prune) { launch_flavour<EL, true, true>(a, nsci, stream); }              \
-                else       { launch_flavour<EL, true, false>(a, nsci, stream); } }           \
-    else      { if (prune) { launch_flavour<EL, false, true>(a, nsci, stream); }             \
-                else       { launch_flavour<EL, false, false>(a, nsci, stream); } }
-    if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF) }
-    else { NBX_DISPATCH(NBX_EL_EWALD_ANA) }
+#define NBX_DISPATCH(EL, VDWC)                                                                 \
+    if (ener) { if (prune) { launch_flavour<EL, true, true, VDWC>(a, nsci, stream); }          \
+                else       { launch_flavour<EL, true, false, VDWC>(a, nsci, stream); } }       \
+    else      { if (prune) { launch_flavour<EL, false, true, VDWC>(a, nsci, stream); }         \
+                else       { launch_flavour<EL, false, false, VDWC>(a, nsci, stream); } }
+    // the twin-range flavour exists for Ewald only (PME load balancing scales rcoulomb, not rvdw)
+    if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF, false) }
+    else if (vdw_cutoff) { NBX_DISPATCH(NBX_EL_EWALD_ANA, true) }
+    else { NBX_DISPATCH(NBX_EL_EWALD_ANA, false) }
 #undef NBX_DISPATCH
     return hipGetLastError();
 }

@@ -196,7 +196,7 @@ def test_bad_inputs_fail_loudly_before_any_launch(nb):
     ip2 = g.system.reaction_field(0.9)
     ip2.rvdw = 0.8
     with pytest.raises(g.gpu.HipError):
-        nb.init_const(ip2, p.ntype, p.nbfp)        # twin-range flavour not built
+        nb.init_const(ip2, p.ntype, p.nbfp)        # rvdw != rcoulomb exists for Ewald only
     with pytest.raises(g.gpu.HipError):
         nb.wait_gpu(0, aloc=2)                     # eatAll is not valid here (nbnxn_cuda.cu:568-574)
 
@@ -349,3 +349,43 @@ def test_device_atomdata_moves_match_host_library(nb):
     assert relrms(fnb, o["f"]) < FORCE_RTOL
     with pytest.raises(g.gpu.HipError):
         nb.add_f(f_part, a0=s.natoms - 10, n=20)
+
+
+def test_twin_range_flavour_and_pme_loadbal_update(nb):
+    """rvdw < rcoulomb (VDW_CUTOFF_CHECK flavours, nbnxn_cuda_kernel.cuh:405-441) against the oracle,
+    reached both ways the reference reaches it: init_const with a twin-range interaction_const_t,
+    and nbnxn_cuda_pme_loadbal_update_param scaling rcoulomb and beta under a fixed rvdw
+    (pme_loadbal.c:704)."""
+    import dataclasses
+    import math
+    s = g.system.water_box(2, 2, 2, model="spce")
+    base = g.system.ewald(0.9, rlist=1.2)
+    p = g.workload.prepare(s, base, 300)
+
+    def twin(rc):
+        beta = g.system.calc_ewaldcoeff_q(rc, 1e-5)
+        return dataclasses.replace(base, rcoulomb=rc, ewaldcoeff_q=beta, sh_ewald=math.erfc(beta * rc))
+
+    def check(ip, f, e):
+        o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+        assert relrms(f, o["f"]) < FORCE_RTOL
+        assert abs(e[0] - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"]) and abs(e[1] - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"])
+        return o
+
+    # equal cut-offs first, then the load balancer moves rcoulomb to 1.1 and on to 1.2 (= rlist)
+    _upload(nb, p, base)
+    o0 = check(base, *nb.compute(p.xq, abi.FORCE_VIRIAL))
+    for rc in (1.1, 1.2):
+        ip = twin(rc)
+        nb.pme_loadbal_update_param(ip.to_struct())
+        o1 = check(ip, *nb.compute(p.xq, abi.FORCE_VIRIAL))
+        f_only, _ = nb.compute(p.xq, 0)
+        assert relrms(f_only, o1["f"]) < FORCE_RTOL
+        assert abs(o1["Vvdw"] - o0["Vvdw"]) < 1e-9 * abs(o0["Vvdw"])     # LJ saw no change: rvdw stayed 0.9
+    # a fresh module state straight from a twin-range interaction_const_t, pruning flavour included
+    ip = twin(1.0)
+    _upload(nb, p, ip)
+    check(ip, *nb.compute(p.xq, abi.FORCE_VIRIAL))
+    # and back to equal cut-offs
+    _upload(nb, p, base)
+    check(base, *nb.compute(p.xq, abi.FORCE_VIRIAL))
