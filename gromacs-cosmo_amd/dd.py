@@ -189,7 +189,8 @@ class HaloExchange:
     def send_x(self):
         """home {x,y,z,q} rows the lower neighbour imports go down; mine arrive from above."""
         torch.index_select(self.xq_t, 0, self.send_slots, out=self.x_out)
-        self.x_out += self.zshift
+        if self.wrap_shift >= 0:
+            self.x_out += self.zshift
         _exchange(self.x_out, self.dom.down, self.x_in, self.dom.up)
         self.xq_t.index_copy_(0, self.halo_slots, self.x_in)
 
@@ -200,6 +201,26 @@ class HaloExchange:
         self.f_t.index_add_(0, self.send_slots, self.f_in)
         if self.wrap_shift >= 0:
             self.fshift_wrap = self.f_in.to(torch.float64).sum(0)
+
+    def add_wrap_fshift(self, out_t):
+        """the same term, added straight into accumulation slot 0 of the engine's output buffer"""
+        if self.wrap_shift >= 0:
+            out_t[2 + 3 * self.wrap_shift:5 + 3 * self.wrap_shift] += self.fshift_wrap.to(out_t.dtype)
+
+
+def reduce_slots(out_t):
+    """Per-step form: the raw accumulation slots summed over ranks in place, ONE collective and no
+    arithmetic kernels; fold_slots() turns them into {e_lj, e_el, fshift} when somebody asks."""
+    if _staged(out_t):
+        h = out_t.cpu()
+        dist.all_reduce(h)
+        out_t.copy_(h)
+    else:
+        dist.all_reduce(out_t)
+
+
+def fold_slots(out_t):
+    return out_t.view(-1, abi.OUT_STRIDE).to(torch.float64).sum(0)
 
 
 def fold_and_reduce(out_t, halo=None):
@@ -245,16 +266,27 @@ class SlabRun:
         assert nb.verify_pairlist(dom.pl_nonlocal, abi.NONLOCAL) == 0
         # first pass the reference way: host xq in, forces out, both lists pruned, streams drained
         self.f_first, self.e_first = nb.compute_both(dom.xq, flags)
-        d_xq, d_f, _ = nb.device_buffers()
-        d_out, nslots, stride = nb.output_slots()
-        assert (nslots, stride) == (abi.OUT_SLOTS, abi.OUT_STRIDE)
+        d_xq, _, _ = nb.device_buffers()
         self.xq_t = torch.as_tensor(_DevArray(d_xq, (dom.npad, 4)), device=self.dev)
-        self.f_t = torch.as_tensor(_DevArray(d_f, (dom.npad, 3)), device=self.dev)
-        self.out_t = torch.as_tensor(_DevArray(d_out, (abi.OUT_SLOTS * abi.OUT_STRIDE,)), device=self.dev)
+        # the clear is folded into the kernel launches: two output buffers alternate, so the
+        # tensors that alias {f, energy slots} are looked up by address after every clear_outputs
+        nb.set_clear_in_kernel(True)
+        self._views = {}
+        self.f_t, self.out_t = self._current_views()
         self.halo = HaloExchange(dom, self.xq_t, self.f_t)
         self.s_loc = torch.cuda.ExternalStream(nb.stream(abi.LOCAL), device=self.dev)
         self.s_nl = torch.cuda.ExternalStream(nb.stream(abi.NONLOCAL), device=self.dev)
-        self.energies = None
+
+    def _current_views(self):
+        _, d_f, _ = self.nb.device_buffers()
+        v = self._views.get(d_f)
+        if v is None:
+            d_out, nslots, stride = self.nb.output_slots()
+            assert (nslots, stride) == (abi.OUT_SLOTS, abi.OUT_STRIDE)
+            v = (torch.as_tensor(_DevArray(d_f, (self.dom.npad, 3)), device=self.dev),
+                 torch.as_tensor(_DevArray(d_out, (abi.OUT_SLOTS * abi.OUT_STRIDE,)), device=self.dev))
+            self._views[d_f] = v
+        return v
 
     @property
     def pair_slots_local(self):
@@ -267,21 +299,29 @@ class SlabRun:
 
     def step(self, ev=None):
         nb, fl = self.nb, self.flags
-        nb.clear_outputs(fl)                              # local stream
+        nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
+        self.f_t, self.out_t = self._current_views()
+        self.halo.f_t = self.f_t
         if ev:
             ev[0].record(self.s_loc)
-        nb.launch_kernel_resident(fl, abi.LOCAL)          # local stream; non-local waits for the clear only
+        nb.launch_kernel_resident(fl, abi.LOCAL)          # local stream; also zeroes the idle output buffer
         if ev:
             ev[1].record(self.s_loc)
         with torch.cuda.stream(self.s_nl):
             self.halo.send_x()                            # overlaps the local kernel
         nb.launch_kernel_resident(fl, abi.NONLOCAL)       # non-local stream, after the halo arrived
         with torch.cuda.stream(self.s_nl):
-            self.s_nl.wait_stream(self.s_loc)             # owner-side adds and the fold see the local kernel done
+            self.s_nl.wait_stream(self.s_loc)             # owner-side adds and the reduction see the local kernel done
             self.halo.return_f()
             if fl & abi.FORCE_VIRIAL:
-                self.energies = fold_and_reduce(self.out_t, self.halo)
+                self.halo.add_wrap_fshift(self.out_t)
+                reduce_slots(self.out_t)
         self.s_loc.wait_stream(self.s_nl)
+
+    def read_energies(self):
+        """{e_lj, e_el, fshift[45][3]} of the last step, summed over ranks (valid until the next step)."""
+        torch.cuda.synchronize(self.dev)
+        return fold_slots(self.out_t)
 
     def forces_home(self):
         """home forces in caller order of this rank's home atoms (after a step)."""

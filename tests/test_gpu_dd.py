@@ -34,7 +34,7 @@ def _worker(rank, world, port, model, ret):
         for _ in range(3):
             run.step()
         f_home = run.forces_home()
-        e = run.energies.cpu().numpy()
+        e = run.read_energies().cpu().numpy()
         glob = g.system.water_box(tiles[0], tiles[1], tiles[2] * world, model=model)
         prep = g.workload.prepare(glob, ip, 0)
         o = O.kernel_gpu_list(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
