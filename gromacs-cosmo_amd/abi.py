@@ -25,6 +25,7 @@ EL_RF, EL_EWALD_ANA = 0, 1
 EEL_CUT, EEL_RF, EEL_GRF, EEL_PME, EEL_EWALD = 0, 1, 2, 3, 4
 VDW_CUT = 0
 MOD_POTSHIFT = 1
+MOD_NONE, MOD_POTSWITCH, MOD_EXACTCUTOFF, MOD_FORCESWITCH = 2, 3, 4, 5
 
 # numpy record layouts of the list elements
 sci_dtype = np.dtype([("sci", "<i4"), ("shift", "<i4"), ("cj4_ind_start", "<i4"), ("cj4_ind_end", "<i4")])

@@ -111,6 +111,9 @@ struct nbnxn_hip {
     int            el_type = NBX_EL_RF;
     float          rcoulomb = 0, rvdw = 0, rlist = 0;
     float          epsfac = 0, k_rf = 0, c_rf = 0, beta = 0, sh_ewald = 0, disp_cpot = 0, rep_cpot = 0;
+    // LJ modifier: 0 cut-off (+ potential shift through the cpot values), 1 force switch, 2 potential switch
+    int            vdw_mod = 0;
+    float          rvdw_switch = 0, fsw[4] = {0, 0, 0, 0}, psw[3] = {0, 0, 0};
     bool           have_const = false;
 
     PList plist[2];
@@ -389,6 +392,17 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
         a.k.rc2      = (float)(b * b * (double)nb->rcoulomb * (double)nb->rcoulomb);
         a.k.rlist2   = (float)(b * b * (double)pl.rlist * (double)pl.rlist);
         a.k.rvdw2    = (float)(b * b * (double)nb->rvdw * (double)nb->rvdw);
+        // switch constants in scaled units: rsw' = beta rsw; a force-switch term c6' (c2 + c3 rsw') rsw'^2 / r'
+        // with c6' = c6 beta^7 must equal (true term) / beta, which gives c2 / beta^9, c3 / beta^10 for
+        // dispersion and c2 / beta^15, c3 / beta^16 for repulsion; potential switch c_n / beta^n
+        a.k.vdw_rsw = (float)(b * (double)nb->rvdw_switch);
+        a.k.fsw_d2  = (float)((double)nb->fsw[0] / std::pow(b, 9));
+        a.k.fsw_d3  = (float)((double)nb->fsw[1] / std::pow(b, 10));
+        a.k.fsw_r2  = (float)((double)nb->fsw[2] / std::pow(b, 15));
+        a.k.fsw_r3  = (float)((double)nb->fsw[3] / std::pow(b, 16));
+        a.k.psw_c3  = (float)((double)nb->psw[0] / std::pow(b, 3));
+        a.k.psw_c4  = (float)((double)nb->psw[1] / std::pow(b, 4));
+        a.k.psw_c5  = (float)((double)nb->psw[2] / std::pow(b, 5));
         a.k.sh       = (float)((double)nb->sh_ewald / b);
         a.k.rep12    = (float)((double)nb->rep_cpot / 12.0 / std::pow(b, 12));
         a.k.ndisp6   = (float)(-(double)nb->disp_cpot / 6.0 / std::pow(b, 6));
@@ -401,7 +415,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     }
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
-    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->rvdw < nb->rcoulomb, st));
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->rvdw < nb->rcoulomb, nb->vdw_mod, st));
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
     nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
     if (a.zero) { nb->clean_other = true; }
@@ -593,9 +607,32 @@ int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type, float rcoulomb, f
     if (check_handle(nb)) { return 1; }
     HIP_TRY(hipSetDevice(nb->device));
     if (set_params(nb, el_type, rcoulomb, rvdw, rlist, epsfac, k_rf, c_rf, ewaldcoeff_q, sh_ewald, disp_cpot, rep_cpot)) { return 1; }
+    nb->vdw_mod = 0; nb->rvdw_switch = 0;   // plain cut-off until nbnxn_hip_set_vdw_modifier_flat says otherwise
     if (upload_nbfp(nb, ntype, nbfp)) { return 1; }
     if (clear_e_fshift(nb)) { return 1; }
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    return 0;
+}
+
+int nbnxn_hip_set_vdw_modifier_flat(nbnxn_hip_ptr_t nb, int vdw_modifier, float rvdw_switch,
+                                    float disp_c2, float disp_c3, float rep_c2, float rep_c3,
+                                    float sw_c3, float sw_c4, float sw_c5)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->have_const) { return nbx_fail("set_vdw_modifier before init_const"); }
+    int mod;
+    if (vdw_modifier == NBX_MOD_NONE || vdw_modifier == NBX_MOD_POTSHIFT) { mod = 0; }
+    else if (vdw_modifier == NBX_MOD_FORCESWITCH) { mod = 1; }
+    else if (vdw_modifier == NBX_MOD_POTSWITCH) { mod = 2; }
+    else { return nbx_fail("VdW modifier %d is not built (cut-off, potential shift, force switch, potential switch are)", vdw_modifier); }
+    if (mod != 0 && !(rvdw_switch >= 0 && rvdw_switch < nb->rvdw))
+    {
+        return nbx_fail("rvdw_switch (%g) must be in [0, rvdw = %g)", rvdw_switch, nb->rvdw);
+    }
+    nb->vdw_mod     = mod;
+    nb->rvdw_switch = mod ? rvdw_switch : 0.0f;
+    nb->fsw[0] = disp_c2; nb->fsw[1] = disp_c3; nb->fsw[2] = rep_c2; nb->fsw[3] = rep_c3;
+    nb->psw[0] = sw_c3; nb->psw[1] = sw_c4; nb->psw[2] = sw_c5;
     return 0;
 }
 
@@ -606,17 +643,20 @@ int nbnxn_hip_init_const(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic, 
     const nbx_atomdata_t *nbat = nbv_group[0].nbat;
     int                   el;
     // flavour choice of nbnxn_cuda_data_mgmt.cu:303-357, reduced to what is built here
-    if (ic->vdwtype != NBX_VDW_CUT || !(ic->vdw_modifier == NBX_MOD_NONE || ic->vdw_modifier == NBX_MOD_POTSHIFT))
+    if (ic->vdwtype != NBX_VDW_CUT)
     {
-        return nbx_fail("VdW type %d / modifier %d is not built yet (plain cut-off with or without potential shift only)", ic->vdwtype, ic->vdw_modifier);
+        return nbx_fail("VdW type %d is not built (cut-off LJ with the shift / switch modifiers is; LJ-PME is not)", ic->vdwtype);
     }
     if (ic->eeltype == NBX_EEL_CUT || ic->eeltype == NBX_EEL_RF || ic->eeltype == NBX_EEL_GRF) { el = NBX_EL_RF; }
     else if (ic->eeltype == NBX_EEL_PME || ic->eeltype == NBX_EEL_EWALD) { el = NBX_EL_EWALD_ANA; }
     else { return nbx_fail("The requested electrostatics type %d is not implemented in the HIP GPU accelerated kernels!", ic->eeltype); }
     // eelCUT runs the RF kernel with k_rf = 0, c_rf = 1/rc as the reference sets them (forcerec.c:2072-2079)
-    return nbnxn_hip_init_const_flat(nb, el, ic->rcoulomb, ic->rvdw, ic->rlist, ic->epsfac, ic->k_rf, ic->c_rf,
-                                     ic->ewaldcoeff_q, ic->sh_ewald, ic->dispersion_shift.cpot, ic->repulsion_shift.cpot,
-                                     nbat->ntype, nbat->nbfp);
+    if (nbnxn_hip_init_const_flat(nb, el, ic->rcoulomb, ic->rvdw, ic->rlist, ic->epsfac, ic->k_rf, ic->c_rf,
+                                  ic->ewaldcoeff_q, ic->sh_ewald, ic->dispersion_shift.cpot, ic->repulsion_shift.cpot,
+                                  nbat->ntype, nbat->nbfp)) { return 1; }
+    return nbnxn_hip_set_vdw_modifier_flat(nb, ic->vdw_modifier, ic->rvdw_switch, ic->dispersion_shift.c2, ic->dispersion_shift.c3,
+                                           ic->repulsion_shift.c2, ic->repulsion_shift.c3, ic->vdw_switch.c3, ic->vdw_switch.c4,
+                                           ic->vdw_switch.c5);
 }
 
 int nbnxn_hip_pme_loadbal_update_param(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic)

@@ -28,6 +28,12 @@ struct nbx_kernel_k_t {
     float escale;      // 1/beta | 1: multiplies the accumulated energies at the end
     float rc2, rlist2; // scaled cut-off and list radius, squared
     float rvdw2;       // scaled LJ cut-off squared (twin-range flavour)
+    // LJ force / potential switch (forcerec.c:1942-1975), in the kernel's scaled units: with
+    // r' = beta r the constants of a term c*rsw^n become c / beta^(n + its prefactor power),
+    // see fill_kernel_consts in nbnxn_hip_api.hip
+    float vdw_rsw;     // scaled rvdw_switch
+    float fsw_d2, fsw_d3, fsw_r2, fsw_r3;   // force switch: dispersion c2, c3; repulsion c2, c3
+    float psw_c3, psw_c4, psw_c5;           // potential switch
     float sh;          // sh_ewald / beta
     float rep12;       // rep_cpot / 12, scaled by beta^-12 for Ewald
     float ndisp6;      // -disp_cpot / 6, scaled by beta^-6 for Ewald
@@ -59,8 +65,9 @@ struct nbx_kernel_args_t {
     int     zero_n4;
 };
 
+// vdw_mod: 0 plain cut-off (with or without potential shift), 1 force switch, 2 potential switch
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune, bool vdw_cutoff,
-                                hipStream_t stream);
+                                int vdw_mod, hipStream_t stream);
 
 // nbnxn_atomdata.hip
 hipError_t nbx_launch_gather_x(const int *a, const float *x, float4 *xq, int begin, int n, hipStream_t stream);

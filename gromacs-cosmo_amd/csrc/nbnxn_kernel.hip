@@ -205,7 +205,7 @@ __device__ __forceinline__ float and_mask(const float v, const int m)
     return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
 }
 
-template <int EL, bool ENER, bool PRUNE, bool VDWC>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
 __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
                                         const float2 c, const unsigned wexcl, const int bitpos, const bool allowed,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
@@ -220,15 +220,58 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     const float inv_r  = __builtin_amdgcn_rsqf(r2);
     const float inv_r2 = inv_r * inv_r;
     const float inv_r6 = inv_r2 * inv_r2 * inv_r2;
-    // (F_lj + F_coulomb) * r^2, as r^-6 (c12 r^-6 - c6) + qq / r
-    float lj6 = inv_r6 * fmaf(c.y, inv_r6, -c.x);
     // twin-range flavour (VDW_CUTOFF_CHECK, nbnxn_cuda_kernel.cuh:405-409, 436-441): rvdw < rcoulomb
-    const bool vdw_in_range = VDWC ? (r2 < a.k.rvdw2) : true;
-    if (VDWC) { lj6 = vdw_in_range ? lj6 : 0.0f; }
-    const float qq  = xi.w * xj.w;
-    // LJ + plain Coulomb vanish for excluded pairs; the reaction-field / Ewald correction stays
-    const float t = and_mask(fmaf(qq, inv_r, lj6) * inv_r2, m);
-    float       F, gv = 0.0f;
+    const bool  vdw_in_range = VDWC ? (r2 < a.k.rvdw2) : true;
+    const float qq = xi.w * xj.w;
+    const float lj6 = inv_r6 * fmaf(c.y, inv_r6, -c.x);     // F_lj * r = c12 r^-12 - c6 r^-6
+    float       t, elj = 0.0f;
+    if (VMOD == 0)
+    {
+        // (F_lj + F_coulomb) * r^2, as r^-6 (c12 r^-6 - c6) + qq / r.  LJ + plain Coulomb vanish for
+        // excluded pairs; the reaction-field / Ewald correction stays
+        const float lj6v = VDWC ? (vdw_in_range ? lj6 : 0.0f) : lj6;
+        t = and_mask(fmaf(qq, inv_r, lj6v) * inv_r2, m);
+        if (ENER)
+        {
+            // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6
+            const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
+            elj = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
+        }
+    }
+    else
+    {
+        // LJ force switch / potential switch (nbnxn_kernel_ref_inner.h:170-205,
+        // nbnxn_cuda_kernel_utils.cuh:84-183), in the kernel's scaled units
+        const float r   = r2 * inv_r;
+        const float rsw = fmaxf(r - a.k.vdw_rsw, 0.0f);
+        float       flj = and_mask(lj6 * inv_r2, m);         // F_lj / r, masked like inv_r6 in the reference
+        const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
+        elj = fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift));
+        if (VMOD == 1)
+        {
+            // the switch force is NOT masked by the exclusion bit in the reference kernels
+            const float rsw2 = rsw * rsw;
+            flj += (c.y * fmaf(a.k.fsw_r3, rsw, a.k.fsw_r2) - c.x * fmaf(a.k.fsw_d3, rsw, a.k.fsw_d2)) * rsw2 * inv_r;
+            if (ENER)
+            {
+                elj += (c.x * fmaf(a.k.fsw_d3 * 0.25f, rsw, a.k.fsw_d2 * (1.0f / 3.0f))
+                        - c.y * fmaf(a.k.fsw_r3 * 0.25f, rsw, a.k.fsw_r2 * (1.0f / 3.0f))) * rsw2 * rsw;
+            }
+            elj = and_mask(elj, m);
+        }
+        else
+        {
+            elj = and_mask(elj, m);
+            const float sw  = fmaf(fmaf(fmaf(a.k.psw_c5, rsw, a.k.psw_c4), rsw, a.k.psw_c3), rsw * rsw * rsw, 1.0f);
+            const float dsw = fmaf(fmaf(5.0f * a.k.psw_c5, rsw, 4.0f * a.k.psw_c4), rsw, 3.0f * a.k.psw_c3) * rsw * rsw;
+            flj = fmaf(flj, sw, -elj * dsw * inv_r);
+            elj *= sw;
+        }
+        if (VDWC) { flj = vdw_in_range ? flj : 0.0f; }
+        t = and_mask(qq * inv_r * inv_r2, m) + flj;
+    }
+    if (VDWC && ENER) { elj = vdw_in_range ? elj : 0.0f; }
+    float F, gv = 0.0f;
     if (EL == NBX_EL_RF) { F = fmaf(qq, -a.k.two_k_rf, t); }
     else
     {
@@ -241,11 +284,7 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     F = cond ? F : 0.0f;
     if (ENER)
     {
-        // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6 = c12 r^-12 - c6 r^-6
-        const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
-        float       elj   = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
-        if (VDWC) { elj = vdw_in_range ? elj : 0.0f; }
-        float       eel;
+        float eel;
         if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf)); }
         else { eel = qq * (and_mask(inv_r - a.k.sh, m) - gv); }
         E_lj += cond ? elj : 0.0f;
@@ -288,7 +327,7 @@ __device__ __forceinline__ void load_jslot(const nbx_kernel_view_t &a, int cj, i
     s.t = a.type[cj * 8 + tidxj];
 }
 
-template <int EL, bool ENER, bool PRUNE, bool VDWC, bool NBFP_LDS, int JM>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS, int JM>
 __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
                                             const unsigned thi, float (&fix)[8], float (&fiy)[8], float (&fiz)[8],
                                             const nbx_jslot_t &s, const int cj, const unsigned wexcl,
@@ -331,7 +370,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_interaction<EL, ENER, PRUNE, VDWC>(a, xi[i], xj, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
+            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
@@ -347,7 +386,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
 #define NBX_KERNEL_WAVES 4
 #endif
 
-template <int EL, bool ENER, bool PRUNE, bool VDWC, bool NBFP_LDS>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KERNEL_WAVES, 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
 {
     NBX_KERNEL_ARGS_FROM_PARAMS
@@ -443,7 +482,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     }
 
 #define NBX_JCLUSTER(JM, SLOT)                                                                             \
-    jcluster<EL, ENER, PRUNE, VDWC, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
+    jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
                                                nfj, E_lj, E_el, ox, oy, oz)
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
@@ -533,28 +572,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     }
 }
 
-template <int EL, bool ENER, bool PRUNE, bool VDWC>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
 void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
 {
-    if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
-    else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+}
+
+template <int EL, bool VDWC, int VMOD>
+void launch_ener_prune(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, hipStream_t stream)
+{
+    if (ener) { if (prune) { launch_flavour<EL, true, true, VDWC, VMOD>(a, nsci, stream); }
+                else       { launch_flavour<EL, true, false, VDWC, VMOD>(a, nsci, stream); } }
+    else      { if (prune) { launch_flavour<EL, false, true, VDWC, VMOD>(a, nsci, stream); }
+                else       { launch_flavour<EL, false, false, VDWC, VMOD>(a, nsci, stream); } }
+}
+
+template <int EL, bool VDWC>
+void launch_vmod(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, int vdw_mod, hipStream_t stream)
+{
+    if (vdw_mod == 1) { launch_ener_prune<EL, VDWC, 1>(a, nsci, ener, prune, stream); }
+    else if (vdw_mod == 2) { launch_ener_prune<EL, VDWC, 2>(a, nsci, ener, prune, stream); }
+    else { launch_ener_prune<EL, VDWC, 0>(a, nsci, ener, prune, stream); }
 }
 
 } // namespace
 
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune, bool vdw_cutoff,
-                                hipStream_t stream)
+                                int vdw_mod, hipStream_t stream)
 {
     if (nsci <= 0) { return hipSuccess; }
-#define NBX_DISPATCH(EL, VDWC)                                                                 \
-    if (ener) { if (prune) { launch_flavour<EL, true, true, VDWC>(a, nsci, stream); }          \
-                else       { launch_flavour<EL, true, false, VDWC>(a, nsci, stream); } }       \
-    else      { if (prune) { launch_flavour<EL, false, true, VDWC>(a, nsci, stream); }         \
-                else       { launch_flavour<EL, false, false, VDWC>(a, nsci, stream); } }
     // the twin-range flavour exists for Ewald only (PME load balancing scales rcoulomb, not rvdw)
-    if (el_type == NBX_EL_RF) { NBX_DISPATCH(NBX_EL_RF, false) }
-    else if (vdw_cutoff) { NBX_DISPATCH(NBX_EL_EWALD_ANA, true) }
-    else { NBX_DISPATCH(NBX_EL_EWALD_ANA, false) }
-#undef NBX_DISPATCH
+    if (el_type == NBX_EL_RF) { launch_vmod<NBX_EL_RF, false>(a, nsci, ener, prune, vdw_mod, stream); }
+    else if (vdw_cutoff) { launch_vmod<NBX_EL_EWALD_ANA, true>(a, nsci, ener, prune, vdw_mod, stream); }
+    else { launch_vmod<NBX_EL_EWALD_ANA, false>(a, nsci, ener, prune, vdw_mod, stream); }
     return hipGetLastError();
 }

@@ -88,6 +88,7 @@ def load():
     lib.nbnxn_hip_last_kernel_ms.argtypes = [vp, ci]
     lib.nbnxn_hip_last_kernel_ms.restype = cf
     lib.nbnxn_hip_set_prune.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_set_vdw_modifier_flat.argtypes = [vp, ci] + [cf] * 8
     lib.nbnxn_hip_set_atom_order.argtypes = [vp, ci, vp, vp]
     lib.nbnxn_hip_upload_xq_flat.argtypes = [vp, vp, ci]
     lib.nbnxn_hip_copy_x_to_xq.argtypes = [vp, vp, ci, ci]
@@ -141,6 +142,8 @@ class NbnxnHip:
         self._chk(self.lib.nbnxn_hip_init_const_flat(self.h, ip.el_type, ip.rcoulomb, ip.rvdw, ip.rlist, ip.epsfac,
                                                      ip.k_rf, ip.c_rf, ip.ewaldcoeff_q, ip.sh_ewald,
                                                      ip.disp_cpot, ip.rep_cpot, ntype, abi.ptr(nbfp)))
+        self._chk(self.lib.nbnxn_hip_set_vdw_modifier_flat(self.h, ip.vdw_modifier, ip.rvdw_switch, ip.disp_c2, ip.disp_c3,
+                                                           ip.rep_c2, ip.rep_c3, ip.sw_c3, ip.sw_c4, ip.sw_c5))
 
     def init_const_struct(self, ic, nbv_group):
         self._chk(self.lib.nbnxn_hip_init_const(self.h, C.byref(ic), C.byref(nbv_group)))

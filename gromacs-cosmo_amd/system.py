@@ -63,12 +63,26 @@ class InteractionParams:
     sh_ewald: float = 0.0
     disp_cpot: float = 0.0
     rep_cpot: float = 0.0
+    # LJ modifier (types/enums.h:92-93) and its constants (forcerec.c:1942-1975)
+    vdw_modifier: int = abi.MOD_POTSHIFT
+    rvdw_switch: float = 0.0
+    disp_c2: float = 0.0
+    disp_c3: float = 0.0
+    rep_c2: float = 0.0
+    rep_c3: float = 0.0
+    sw_c3: float = 0.0
+    sw_c4: float = 0.0
+    sw_c5: float = 0.0
 
     def to_struct(self):
         ic = abi.InteractionConst()
         ic.vdwtype = abi.VDW_CUT
-        ic.vdw_modifier = abi.MOD_POTSHIFT
+        ic.vdw_modifier = self.vdw_modifier
         ic.rvdw = self.rvdw
+        ic.rvdw_switch = self.rvdw_switch
+        ic.dispersion_shift.c2, ic.dispersion_shift.c3 = self.disp_c2, self.disp_c3
+        ic.repulsion_shift.c2, ic.repulsion_shift.c3 = self.rep_c2, self.rep_c3
+        ic.vdw_switch.c3, ic.vdw_switch.c4, ic.vdw_switch.c5 = self.sw_c3, self.sw_c4, self.sw_c5
         ic.dispersion_shift.cpot = self.disp_cpot
         ic.repulsion_shift.cpot = self.rep_cpot
         ic.sh_invrc6 = -self.disp_cpot
@@ -85,6 +99,31 @@ class InteractionParams:
         ic.k_rf = self.k_rf
         ic.c_rf = self.c_rf
         return ic
+
+
+def _force_switch_constants(p, rsw, rc):
+    """force_switch_constants, forcerec.c:1942-1957."""
+    c2 = ((p + 1) * rsw - (p + 4) * rc) / (rc ** (p + 2) * (rc - rsw) ** 2)
+    c3 = -((p + 1) * rsw - (p + 3) * rc) / (rc ** (p + 2) * (rc - rsw) ** 3)
+    cpot = -rc ** -p + p * c2 / 3 * (rc - rsw) ** 3 + p * c3 / 4 * (rc - rsw) ** 4
+    return c2, c3, cpot
+
+
+def with_force_switch(ip, rvdw_switch):
+    """vdw-modifier = force-switch (eintmodFORCESWITCH, forcerec.c:2020-2026)."""
+    import dataclasses
+    d2, d3, dp = _force_switch_constants(6.0, rvdw_switch, ip.rvdw)
+    r2, r3, rp = _force_switch_constants(12.0, rvdw_switch, ip.rvdw)
+    return dataclasses.replace(ip, vdw_modifier=abi.MOD_FORCESWITCH, rvdw_switch=rvdw_switch,
+                               disp_c2=d2, disp_c3=d3, disp_cpot=dp, rep_c2=r2, rep_c3=r3, rep_cpot=rp)
+
+
+def with_potential_switch(ip, rvdw_switch):
+    """vdw-modifier = potential-switch (eintmodPOTSWITCH, forcerec.c:1959-1975, 2027-2031): no shift."""
+    import dataclasses
+    d = ip.rvdw - rvdw_switch
+    return dataclasses.replace(ip, vdw_modifier=abi.MOD_POTSWITCH, rvdw_switch=rvdw_switch, disp_cpot=0.0, rep_cpot=0.0,
+                               sw_c3=-10 * d ** -3, sw_c4=15 * d ** -4, sw_c5=-6 * d ** -5)
 
 
 def calc_ewaldcoeff_q(rc, rtol):

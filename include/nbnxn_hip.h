@@ -46,7 +46,8 @@ enum { NBX_LOCAL = 0, NBX_NONLOCAL = 1 };
 /* eeltype / vdwtype / modifier values this module accepts (types/enums.h:92-122) */
 enum { NBX_EEL_CUT = 0, NBX_EEL_RF = 1, NBX_EEL_GRF = 2, NBX_EEL_PME = 3, NBX_EEL_EWALD = 4 };
 enum { NBX_VDW_CUT = 0 };
-enum { NBX_MOD_POTSHIFT_VERLET = 0, NBX_MOD_POTSHIFT = 1, NBX_MOD_NONE = 2 };
+enum { NBX_MOD_POTSHIFT_VERLET = 0, NBX_MOD_POTSHIFT = 1, NBX_MOD_NONE = 2, NBX_MOD_POTSWITCH = 3,
+       NBX_MOD_EXACTCUTOFF = 4, NBX_MOD_FORCESWITCH = 5 };   /* enum eintmod, types/enums.h:92-93 */
 
 /* electrostatics flavour of the device kernel (nbnxn_cuda/nbnxn_cuda_types.h:80-82) */
 enum { NBX_EL_RF = 0, NBX_EL_EWALD_ANA = 1, NBX_EL_NR };
@@ -351,6 +352,14 @@ int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type,
                               int ntype, const float *nbfp);
 
 /* = nbnxn_hip_init_pairlist */
+/* LJ modifier of interaction_const_t for hosts that use init_const_flat (the struct-taking
+ * nbnxn_hip_init_const reads it from ic): vdw_modifier is enum eintmod (NBX_MOD_*), the
+ * constants are ic->rvdw_switch, dispersion_shift.c2/c3, repulsion_shift.c2/c3, vdw_switch.c3/c4/c5
+ * (forcerec.c:1942-1975).  The cpot values travel with init_const_flat.  Call after init_const_flat. */
+int nbnxn_hip_set_vdw_modifier_flat(nbnxn_hip_ptr_t nb, int vdw_modifier, float rvdw_switch,
+                                    float disp_c2, float disp_c3, float rep_c2, float rep_c3,
+                                    float sw_c3, float sw_c4, float sw_c5);
+
 int nbnxn_hip_init_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc, float rlist,
                                  int nsci, const nbx_sci_t *sci,
                                  int ncj4, const nbx_cj4_t *cj4,

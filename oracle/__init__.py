@@ -17,7 +17,10 @@ class OracleParams(C.Structure):
                 ("rcoulomb", C.c_double), ("rvdw", C.c_double),
                 ("epsfac", C.c_double), ("k_rf", C.c_double), ("c_rf", C.c_double),
                 ("beta", C.c_double), ("sh_ewald", C.c_double),
-                ("disp_cpot", C.c_double), ("rep_cpot", C.c_double)]
+                ("disp_cpot", C.c_double), ("rep_cpot", C.c_double),
+                ("vdw_modifier", C.c_int), ("rvdw_switch", C.c_double),
+                ("disp_c2", C.c_double), ("disp_c3", C.c_double), ("rep_c2", C.c_double), ("rep_c3", C.c_double),
+                ("sw_c3", C.c_double), ("sw_c4", C.c_double), ("sw_c5", C.c_double)]
 
 
 class RefParams(C.Structure):
@@ -25,7 +28,10 @@ class RefParams(C.Structure):
                 ("rcoulomb", C.c_float), ("rvdw", C.c_float), ("rlist", C.c_float),
                 ("epsfac", C.c_float), ("k_rf", C.c_float), ("c_rf", C.c_float),
                 ("ewaldcoeff_q", C.c_float), ("sh_ewald", C.c_float),
-                ("disp_cpot", C.c_float), ("rep_cpot", C.c_float)]
+                ("disp_cpot", C.c_float), ("rep_cpot", C.c_float),
+                ("vdw_modifier", C.c_int), ("rvdw_switch", C.c_float),
+                ("disp_c2", C.c_float), ("disp_c3", C.c_float), ("rep_c2", C.c_float), ("rep_c3", C.c_float),
+                ("sw_c3", C.c_float), ("sw_c4", C.c_float), ("sw_c5", C.c_float)]
 
 
 def _p(a):
@@ -36,12 +42,20 @@ def oracle_params(ip):
     """ip: gromacs_cosmo_amd.system.InteractionParams (float32-rounded like the C structs)."""
     f = lambda v: float(np.float32(v))
     return OracleParams(ip.el_type, f(ip.rcoulomb), f(ip.rvdw), f(ip.epsfac), f(ip.k_rf), f(ip.c_rf),
-                        f(ip.ewaldcoeff_q), f(ip.sh_ewald), f(ip.disp_cpot), f(ip.rep_cpot))
+                        f(ip.ewaldcoeff_q), f(ip.sh_ewald), f(ip.disp_cpot), f(ip.rep_cpot),
+                        int(getattr(ip, "vdw_modifier", 1)), f(getattr(ip, "rvdw_switch", 0.0)),
+                        f(getattr(ip, "disp_c2", 0.0)), f(getattr(ip, "disp_c3", 0.0)),
+                        f(getattr(ip, "rep_c2", 0.0)), f(getattr(ip, "rep_c3", 0.0)),
+                        f(getattr(ip, "sw_c3", 0.0)), f(getattr(ip, "sw_c4", 0.0)), f(getattr(ip, "sw_c5", 0.0)))
 
 
 def ref_params(ip):
     return RefParams(ip.el_type, ip.rcoulomb, ip.rvdw, ip.rlist, ip.epsfac, ip.k_rf, ip.c_rf,
-                     ip.ewaldcoeff_q, ip.sh_ewald, ip.disp_cpot, ip.rep_cpot)
+                     ip.ewaldcoeff_q, ip.sh_ewald, ip.disp_cpot, ip.rep_cpot,
+                     int(getattr(ip, "vdw_modifier", 1)), getattr(ip, "rvdw_switch", 0.0),
+                     getattr(ip, "disp_c2", 0.0), getattr(ip, "disp_c3", 0.0), getattr(ip, "rep_c2", 0.0),
+                     getattr(ip, "rep_c3", 0.0), getattr(ip, "sw_c3", 0.0), getattr(ip, "sw_c4", 0.0),
+                     getattr(ip, "sw_c5", 0.0))
 
 
 _oracle = None

@@ -41,6 +41,12 @@ typedef struct {
     double k_rf, c_rf;
     double beta, sh_ewald;
     double disp_cpot, rep_cpot;
+    /* LJ modifier: enum eintmod (types/enums.h:92-93): 1 potential shift, 3 potential switch,
+     * 5 force switch; constants of forcerec.c:1942-1975 */
+    int    vdw_modifier;
+    double rvdw_switch;
+    double disp_c2, disp_c3, rep_c2, rep_c3;
+    double sw_c3, sw_c4, sw_c5;
 } oracle_params_t;
 
 /* Pair term shared by the list kernel and the brute-force sum.
@@ -76,15 +82,37 @@ static double pair_term(const oracle_params_t *p, double rsq, int int_bit,
 
     if (rsq < p->rvdw * p->rvdw)
     {
-        /* kernel_ref_inner.h:158-165, kernel_gpu_ref.c:291-312 */
+        /* kernel_ref_inner.h:157-205 (kernel_gpu_ref.c:291-312 for the plain cut-off) */
+        double frLJ, VLJ, rsw = 0;
         rinvsix = int_bit * rinvsq * rinvsq * rinvsq;
         const double frLJ6  = c6 * rinvsix;
         const double frLJ12 = c12 * rinvsix * rinvsix;
-        fscal += (frLJ12 - frLJ6) * rinvsq;
-        if (vv)
+        frLJ = frLJ12 - frLJ6;                       /* force times r */
+        VLJ  = (frLJ12 + c12 * p->rep_cpot) / 12.0 - (frLJ6 + c6 * p->disp_cpot) / 6.0;
+        if (p->vdw_modifier == 5 || p->vdw_modifier == 3)
         {
-            *vv += int_bit * ((frLJ12 + c12 * p->rep_cpot) / 12.0 - (frLJ6 + c6 * p->disp_cpot) / 6.0);
+            rsw = r - p->rvdw_switch;
+            rsw = rsw >= 0.0 ? rsw : 0.0;
         }
+        if (p->vdw_modifier == 5)
+        {
+            /* force switch :176-185; like the reference it is NOT masked by int_bit */
+            frLJ += -c6 * (p->disp_c2 + p->disp_c3 * rsw) * rsw * rsw * r
+                + c12 * (p->rep_c2 + p->rep_c3 * rsw) * rsw * rsw * r;
+            VLJ  += -c6 * (-p->disp_c2 / 3 - p->disp_c3 / 4 * rsw) * rsw * rsw * rsw
+                + c12 * (-p->rep_c2 / 3 - p->rep_c3 / 4 * rsw) * rsw * rsw * rsw;
+        }
+        VLJ *= int_bit;                               /* :187-193 */
+        if (p->vdw_modifier == 3)
+        {
+            /* potential switch :195-205 */
+            const double sw  = 1.0 + (p->sw_c3 + (p->sw_c4 + p->sw_c5 * rsw) * rsw) * rsw * rsw * rsw;
+            const double dsw = (3 * p->sw_c3 + (4 * p->sw_c4 + 5 * p->sw_c5 * rsw) * rsw) * rsw * rsw;
+            frLJ = frLJ * sw - r * VLJ * dsw;
+            VLJ *= sw;
+        }
+        fscal += frLJ * rinvsq;
+        if (vv) { *vv += VLJ; }
     }
     return fscal;
 }

@@ -119,14 +119,26 @@ typedef struct {
     float epsfac, k_rf, c_rf;
     float ewaldcoeff_q, sh_ewald;
     float disp_cpot, rep_cpot;
+    int   vdw_modifier;   /* enum eintmod */
+    float rvdw_switch;
+    float disp_c2, disp_c3, rep_c2, rep_c3;
+    float sw_c3, sw_c4, sw_c5;
 } ref_params_t;
 
 static void make_ic(const ref_params_t *p, interaction_const_t *ic)
 {
     memset(ic, 0, sizeof(*ic));
     ic->vdwtype               = evdwCUT;
-    ic->vdw_modifier          = eintmodPOTSHIFT;
+    ic->vdw_modifier          = p->vdw_modifier;
     ic->rvdw                  = p->rvdw;
+    ic->rvdw_switch           = p->rvdw_switch;
+    ic->dispersion_shift.c2   = p->disp_c2;
+    ic->dispersion_shift.c3   = p->disp_c3;
+    ic->repulsion_shift.c2    = p->rep_c2;
+    ic->repulsion_shift.c3    = p->rep_c3;
+    ic->vdw_switch.c3         = p->sw_c3;
+    ic->vdw_switch.c4         = p->sw_c4;
+    ic->vdw_switch.c5         = p->sw_c5;
     ic->dispersion_shift.cpot = p->disp_cpot;
     ic->repulsion_shift.cpot  = p->rep_cpot;
     ic->sh_invrc6             = -p->disp_cpot;

@@ -41,6 +41,23 @@ def small_case(name, system, ip, mcb=0):
           f"ref Vvdw {r_ref['Vvdw']:.6e} Vc {r_ref['Vc']:.6e}  gpu_ref Vvdw {r_gpu['Vvdw']:.6e} Vc {r_gpu['Vc']:.6e}")
 
 
+XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c3", "sw_c3", "sw_c4", "sw_c5"]
+
+
+def switch_case(name, system, ip, mcb=0):
+    """LJ force / potential switch: only nbnxn_kernel_ref has these flavours (nbnxn_kernel_gpu_ref
+    is plain cut-off LJ), so the fixture holds its outputs alone."""
+    p = g.workload.prepare(system, ip, mcb)
+    r_ref = O.RefKernelRef(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip).run(calc_ener=True)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        params=params_array(ip), params_ext=np.array([getattr(ip, k) for k in XFIELDS], dtype=np.float64),
+        xq=p.xq, type=p.type, ntype=p.ntype, nbfp=p.nbfp, shift_vec=p.shift_vec,
+        sci=p.pl.sci, cj4=p.pl.cj4, excl=p.pl.excl, nci_tot=p.pl.nci_tot,
+        ref_f=r_ref["f"], ref_fshift=r_ref["fshift"], ref_Vc=r_ref["Vc"], ref_Vvdw=r_ref["Vvdw"])
+    print(f"{name}: natoms {len(p.xq)} nsci {p.pl.nsci} ncj4 {p.pl.ncj4} ref Vvdw {r_ref['Vvdw']:.6e} Vc {r_ref['Vc']:.6e}")
+
+
 def large_case(name, tiles, model, ip, stride=97):
     """97k atoms: the inputs are regenerated from the seedless tiling recipe by the test; only
     the reference's outputs (energies, shift forces, every `stride`-th atom's force in grid
@@ -68,5 +85,11 @@ if __name__ == "__main__":
     small_case("spce3240_ewald09", g.system.water_box(5, 1, 1, model="spce"), g.system.ewald(0.9))
     small_case("ljchain2000_rf", g.system.lj_chain_mixture(2000, ntype=8, seed=2026), g.system.reaction_field(0.9, epsilon_rf=0.0))
     small_case("ljchain2000_ewald", g.system.lj_chain_mixture(2000, ntype=8, seed=2026), g.system.ewald(0.9), mcb=400)
+    switch_case("spc648_rf09_fswitch07", g.system.water_box(1, 1, 1),
+                g.system.with_force_switch(g.system.reaction_field(0.9), 0.7))
+    switch_case("ljchain1000_ewald09_pswitch07", g.system.lj_chain_mixture(1000, ntype=8, seed=2026),
+                g.system.with_potential_switch(g.system.ewald(0.9), 0.7))
+    switch_case("ljchain1000_ewald09_fswitch07", g.system.lj_chain_mixture(1000, ntype=8, seed=2026),
+                g.system.with_force_switch(g.system.ewald(0.9), 0.7), mcb=100)
     large_case("spc97k_rf10", (5, 5, 6), "spc", g.system.reaction_field(1.0))
     large_case("spce97k_ewald10", (5, 5, 6), "spce", g.system.ewald(1.0))

@@ -389,3 +389,63 @@ def test_twin_range_flavour_and_pme_loadbal_update(nb):
     # and back to equal cut-offs
     _upload(nb, p, base)
     check(base, *nb.compute(p.xq, abi.FORCE_VIRIAL))
+
+
+@pytest.mark.parametrize("el", ["rf", "ewald"])
+@pytest.mark.parametrize("mod", ["force-switch", "potential-switch"])
+def test_lj_switch_flavours(nb, el, mod):
+    """vdw-modifier = force-switch / potential-switch (nbnxn_kernel_ref_inner.h:170-205,
+    nbnxn_cuda_kernel_utils.cuh:84-183) against the oracle, whose switch arithmetic is pinned to the
+    reference's nbnxn_kernel_ref in tests/test_oracle_golden.py.  Water (O-O LJ only) and the
+    8-type chain mixture; F+V, F-only and prune flavours; through the struct entry point as well."""
+    base = g.system.reaction_field(0.9) if el == "rf" else g.system.ewald(0.9)
+    ip = (g.system.with_force_switch if mod == "force-switch" else g.system.with_potential_switch)(base, 0.7)
+    for s in (g.system.water_box(5, 1, 1, model="spce"), g.system.lj_chain_mixture(3000)):
+        p = g.workload.prepare(s, ip, 200)
+        o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+        o_shift = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, base)
+        # the modifier is visible well above the parity tolerance (in the LJ energy; the forces of the chain
+        # mixture are dominated by close contacts the switch does not touch)
+        assert abs(o_shift["Vvdw"] - o["Vvdw"]) > 10 * ENERGY_RTOL * abs(o["Vvdw"])
+        _upload(nb, p, ip)
+        f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)          # prune + energies
+        _check_against(f, e, p, ip, o)
+        f2, _ = nb.compute(p.xq, 0)                        # force only, pruned list
+        assert relrms(f2, o["f"]) < FORCE_RTOL
+        f3, e3 = nb.compute(p.xq, abi.FORCE_VIRIAL)        # energies, pruned list
+        _check_against(f3, e3, p, ip, o)
+        # back to the plain cut-off on the same handle: no modifier state may leak
+        _upload(nb, p, base)
+        f4, e4 = nb.compute(p.xq, abi.FORCE_VIRIAL)
+        _check_against(f4, e4, p, base, o_shift)
+
+
+def test_force_switch_with_twin_range(nb):
+    """force switch to rvdw = 0.9 under rcoulomb = 1.1 (what PME load balancing does to a CHARMM-style
+    set-up): the switch polynomial is not zero beyond rvdw, the cut-off check has to remove it."""
+    import dataclasses
+    import math
+    s = g.system.lj_chain_mixture(4000)
+    base = g.system.with_force_switch(g.system.ewald(0.9, rlist=1.2), 0.75)
+    p = g.workload.prepare(s, base, 300)
+    beta = g.system.calc_ewaldcoeff_q(1.1, 1e-5)
+    ip = dataclasses.replace(base, rcoulomb=1.1, ewaldcoeff_q=beta, sh_ewald=math.erfc(beta * 1.1))
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    _upload(nb, p, ip)
+    _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ip, o)
+    # and reached through the load balancer's call
+    _upload(nb, p, base)
+    nb.compute(p.xq, abi.FORCE_VIRIAL)
+    nb.pme_loadbal_update_param(ip.to_struct())
+    _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ip, o)
+
+
+@pytest.mark.parametrize("name", __import__("util").SWITCH)
+def test_lj_switch_fixtures_from_the_reference_kernel(nb, name):
+    """the HIP kernels straight against the reference's nbnxn_kernel_ref outputs for the switch flavours"""
+    p, ip, d = load_small(name)
+    _upload(nb, p, ip)
+    f, (elj, eel, fsh) = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert relrms(f, d["ref_f"]) < FORCE_RTOL
+    assert abs(elj - float(d["ref_Vvdw"])) < 2e-5 * abs(float(d["ref_Vvdw"]))
+    assert abs(eel - float(d["ref_Vc"])) < 1e-3 * abs(float(d["ref_Vc"]))    # one-float accumulation in the reference

@@ -26,16 +26,23 @@ def relrms(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 
 
-def params_from_array(arr):
+XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c3", "sw_c3", "sw_c4", "sw_c5"]
+SWITCH = ["spc648_rf09_fswitch07", "ljchain1000_ewald09_pswitch07", "ljchain1000_ewald09_fswitch07"]
+
+
+def params_from_array(arr, ext=None):
     kw = {k: float(v) for k, v in zip(PFIELDS, arr)}
     kw["el_type"] = int(kw["el_type"])
+    if ext is not None:
+        kw.update({k: float(v) for k, v in zip(XFIELDS, ext)})
+        kw["vdw_modifier"] = int(kw["vdw_modifier"])
     return InteractionParams(**kw)
 
 
 def load_small(name):
     """A golden fixture as (prepared-like namespace, ip, dict of reference outputs)."""
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
-    ip = params_from_array(d["params"])
+    ip = params_from_array(d["params"], d["params_ext"] if "params_ext" in d.files else None)
     pl = PairList(d["sci"].copy(), d["cj4"].copy(), d["excl"].copy(), int(d["nci_tot"]), ip.rlist)
     p = SimpleNamespace(xq=d["xq"].copy(), type=d["type"].copy(), ntype=int(d["ntype"]), nbfp=d["nbfp"].copy(),
                         shift_vec=d["shift_vec"].copy(), pl=pl, natoms=len(d["xq"]))

@@ -8,8 +8,8 @@ cur=None
 for l in sys.stdin:
     m=re.search(r"Function Name: (\S+)",l)
     if m:
-        n=m.group(1); k=re.search(r"nbnxn_kernel(_v\d)?ILi(\d)ELb(\d)ELb(\d)ELb(\d)",n)
-        cur="k"+" el%s ener%s prune%s lds%s"%k.groups()[1:] if k else n[:40]; d={}
+        n=m.group(1); k=re.search(r"nbnxn_kernel(_v\d)?ILi(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)",n)
+        cur="k el%s ener%s prune%s vdwc%s vmod%s lds%s"%k.groups()[1:] if k else n[:40]; d={}
         continue
     for key in ("VGPRs:","VGPRs Spill:","Occupancy [waves/SIMD]:","LDS Size [bytes/block]:","ScratchSize [bytes/lane]:"):
         if key in l:
