@@ -35,6 +35,20 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 DT_FS = 2.0
 
 
+def oracle_check(prep, ip, f_gpu, e_gpu):
+    """Checker leg (runs with the CPU baseline, outside every timed region): the double-precision
+    oracle over the same list gives the parity of THIS run's forces and energies and the
+    reference's three pair counts (nbnxn_kernel_gpu_ref.c:362-375)."""
+    import oracle as O
+    o = O.kernel_gpu_list(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
+    fo = np.asarray(o["f"], dtype=np.float64)
+    err = float(np.sqrt(((f_gpu.astype(np.float64) - fo) ** 2).sum() / (fo ** 2).sum()))
+    return {"force_rel_rms_vs_oracle": err,
+            "e_lj_rel": abs(e_gpu[0] - o["Vvdw"]) / abs(o["Vvdw"]), "e_el_rel": abs(e_gpu[1] - o["Vc"]) / abs(o["Vc"]),
+            "pair_slots": int(o["counts"][0]), "pair_slots_after_prune": int(o["counts"][1]),
+            "pairs_in_cutoff_non_filler": int(o["counts"][2])}
+
+
 def cpu_baseline(prep, ip, seconds=12.0):
     """The reference's plain-C nbnxn_kernel_ref (oracle/_ref, compiled from the reference tree)
     on the host cores, same atoms and pairs (as a 4x4 list); falls back to the repo's scalar
@@ -126,7 +140,7 @@ def main():
         pair_slots = prep.pair_slots
         roof_slots = prep.pair_slots
         # coordinates resident in HBM; this first call also prunes the fresh list
-        f0, _ = nb.compute(prep.xq, flags)
+        f0, e0 = nb.compute(prep.xq, abi.FORCE_VIRIAL)
 
         def step(ev=None):
             nb.clear_outputs(flags)
@@ -225,6 +239,9 @@ def main():
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(prep, ip)
             out["cpu_baseline"] = cb
+            chk = oracle_check(prep, ip, f0, e0)
+            out["parity"] = chk
+            out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
