@@ -21,9 +21,10 @@ FORCE_ENERGY = 1 << 9
 LOCAL, NONLOCAL = 0, 1
 # accumulation slots of the device output buffer (csrc/nbnxn_kernel.h)
 OUT_SLOTS, OUT_STRIDE = 64, 144
-EL_RF, EL_EWALD_ANA = 0, 1
+EL_RF, EL_EWALD_ANA, EL_EWALD_TAB = 0, 1, 2
 EEL_CUT, EEL_RF, EEL_GRF, EEL_PME, EEL_EWALD = 0, 1, 2, 3, 4
-VDW_CUT = 0
+VDW_CUT, VDW_PME = 0, 5
+LJCR_GEOM, LJCR_LB, LJCR_NONE = 0, 1, 2
 MOD_POTSHIFT = 1
 MOD_NONE, MOD_POTSWITCH, MOD_EXACTCUTOFF, MOD_FORCESWITCH = 2, 3, 4, 5
 

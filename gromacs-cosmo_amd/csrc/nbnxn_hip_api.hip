@@ -114,6 +114,13 @@ struct nbnxn_hip {
     // LJ modifier: 0 cut-off (+ potential shift through the cpot values), 1 force switch, 2 potential switch
     int            vdw_mod = 0;
     float          rvdw_switch = 0, fsw[4] = {0, 0, 0, 0}, psw[3] = {0, 0, 0};
+    // LJ-PME (vdw_mod 3): grid C6 per type pair, Ewald coefficient and potential shift of the dispersion mesh
+    DevBuf<float>  c6grid;
+    float          ewaldcoeff_lj = 0, sh_lj_ewald = 0;
+    // tabulated Ewald (el_type NBX_EL_EWALD_TAB): force table divided by beta^2
+    DevBuf<float>  coulomb_tab;
+    int            tab_size = 0;
+    float          tab_scale = 0, tab_beta = 0, tab_rc = 0;
     bool           have_const = false;
 
     PList plist[2];
@@ -162,10 +169,61 @@ void loc_range(const nbnxn_hip *nb, int loc, int *begin, int *len)
     else { *begin = nb->natoms_local; *len = nb->natoms - nb->natoms_local; }
 }
 
+// Ewald long-range force table F(r) = -d/dr [erf(beta r) / r] at ntab points of spacing dx, made
+// the way table_spline3_fill_ewald_lr does for the reference's GPU table (tables.c:165-311,
+// called from nbnxn_cuda_data_mgmt.cu:134): a quadratic spline is laid through the potential
+// at the table points and interval midpoints, and the tabulated force at a point is the mean of
+// the spline derivatives of the two intervals that meet there -- which makes LINEAR
+// interpolation of the force table consistent with the quadratic spline energy.  erf(beta r) / r
+// is finite everywhere, so the reference's out-of-range continuation (:218-222, for the r^-6
+// LJ table) has nothing to do here.
+void make_ewald_force_table(std::vector<float> &tab, int ntab, double dx, double beta)
+{
+    auto v_lr = [beta](double r) { return r == 0 ? beta * 2 / std::sqrt(M_PI) : std::erf(beta * r) / r; };
+    tab.assign(ntab, 0.0f);
+    for (int hi = ntab - 1; hi >= 1; hi--)
+    {
+        // interval (hi-1, hi): spline s(x) = v_hi + d_hi (x - x_hi) + curvature term, with the
+        // derivative at the upper end chosen so that the quadratic reproduces the potential at
+        // both ends and at the midpoint on average (tables.c:244-252), and the derivative at
+        // the lower end following from the two end values (:268-277)
+        const double x_hi = hi * dx;
+        const double v_hi = v_lr(x_hi), v_lo = v_lr((hi - 1) * dx), v_mid = v_lr(x_hi - 0.5 * dx);
+        const double d_hi = (v_hi - v_lo) / dx + 2.0 * (v_hi + v_lo - 2.0 * v_mid) / dx;
+        const double d_lo = d_hi - 2.0 * (d_hi * dx + v_lo - v_hi) / dx;
+        // each inner point gets half of either side; the float roundings are those of the
+        // reference's real-typed table (store the half from above first, then add the half from below)
+        if (hi == ntab - 1) { tab[hi] = (float)(-d_hi); }
+        else { tab[hi] = (float)((double)tab[hi] - 0.5 * d_hi); }
+        tab[hi - 1] = (float)(-0.5 * d_lo);
+    }
+    tab[0] *= 2;   // the first point only has an interval above it
+}
+
+int upload_coulomb_tab(nbnxn_hip *nb, float beta, float rcoulomb)
+{
+    if (nb->coulomb_tab.p && nb->tab_beta == beta && nb->tab_rc == rcoulomb) { return 0; }
+    // GPU_EWALD_COULOMB_FORCE_TABLE_SIZE and the "- 2" of nbnxn_cuda_data_mgmt.cu:128-130
+    const int    ntab  = 1536;
+    const double scale = (ntab - 2) / (double)rcoulomb;
+    std::vector<float> tab;
+    make_ewald_force_table(tab, ntab, 1.0 / scale, beta);
+    // the kernel works in beta-scaled coordinates: F / beta^2, index = (beta r) * (scale / beta)
+    for (float &t : tab) { t = (float)((double)t / ((double)beta * (double)beta)); }
+    if (dev_reserve(nb->coulomb_tab, (size_t)ntab)) { return 1; }
+    HIP_TRY(hipMemcpyAsync(nb->coulomb_tab.p, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice, nb->stream[0]));
+    HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    nb->tab_size = ntab; nb->tab_scale = (float)scale; nb->tab_beta = beta; nb->tab_rc = rcoulomb;
+    return 0;
+}
+
 int set_params(nbnxn_hip *nb, int el_type, float rcoulomb, float rvdw, float rlist, float epsfac,
                float k_rf, float c_rf, float beta, float sh_ewald, float disp_cpot, float rep_cpot)
 {
-    if (el_type != NBX_EL_RF && el_type != NBX_EL_EWALD_ANA) { return nbx_fail("unsupported electrostatics flavour %d", el_type); }
+    if (el_type != NBX_EL_RF && el_type != NBX_EL_EWALD_ANA && el_type != NBX_EL_EWALD_TAB)
+    {
+        return nbx_fail("unsupported electrostatics flavour %d", el_type);
+    }
     if (!(rcoulomb > 0)) { return nbx_fail("rcoulomb must be > 0"); }
     // twin-range: only rvdw < rcoulomb with Ewald (what PME load balancing produces and the only
     // combination the Verlet scheme allows, readir.c / nbnxn_cuda_data_mgmt.cu:303-357)
@@ -174,7 +232,9 @@ int set_params(nbnxn_hip *nb, int el_type, float rcoulomb, float rvdw, float rli
     {
         return nbx_fail("rvdw (%g) != rcoulomb (%g) with reaction field: the Verlet scheme has no such flavour", rvdw, rcoulomb);
     }
-    if (el_type == NBX_EL_EWALD_ANA && beta * beta * rcoulomb * rcoulomb > 16.0f)
+    if (el_type != NBX_EL_RF && !(beta > 0)) { return nbx_fail("ewaldcoeff_q must be > 0 for the Ewald flavours"); }
+    // the energies of the tabulated flavour are analytical too (as in the reference), so the fit's range binds both
+    if (el_type != NBX_EL_RF && beta * beta * rcoulomb * rcoulomb > 16.0f)
     {
         return nbx_fail("(ewaldcoeff_q*rcoulomb)^2 = %g exceeds the range (16) of the analytical Ewald fit", beta * beta * rcoulomb * rcoulomb);
     }
@@ -183,6 +243,9 @@ int set_params(nbnxn_hip *nb, int el_type, float rcoulomb, float rvdw, float rli
     nb->epsfac = epsfac; nb->k_rf = k_rf; nb->c_rf = c_rf;
     nb->beta = beta; nb->sh_ewald = sh_ewald;
     nb->disp_cpot = disp_cpot; nb->rep_cpot = rep_cpot;
+    // (re)tabulate like init_ewald_coulomb_force_table, also on PME load-balancing updates
+    // (nbnxn_cuda_data_mgmt.cu:597-606)
+    if (el_type == NBX_EL_EWALD_TAB && upload_coulomb_tab(nb, beta, rcoulomb)) { return 1; }
     nb->have_const = true;
     return 0;
 }
@@ -372,6 +435,9 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     nbx_kernel_args_t a;
     a.xq = nb->xq.p; a.f = nb->f.p; a.type = nb->type.p; a.shift_vec = nb->shift_vec; a.ntype = nb->ntype;
     a.nbfp = nb->nbfp.p;
+    a.c6grid = nb->c6grid.p; a.coulomb_tab = nb->coulomb_tab.p;
+    if (nb->vdw_mod == 3 && !a.c6grid) { return nbx_fail("LJ-PME launch without the grid C6 table"); }
+    if (nb->el_type == NBX_EL_EWALD_TAB && !a.coulomb_tab) { return nbx_fail("tabulated Ewald launch without the force table"); }
     a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p; a.out = nb->out;
     a.zero = nullptr; a.zero_n4 = 0;
     if (nb->clear_in_kernel && iloc == NBX_LOCAL)
@@ -408,6 +474,14 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
         a.k.ndisp6   = (float)(-(double)nb->disp_cpot / 6.0 / std::pow(b, 6));
         // E_self = -c q_raw^2 epsfac with c = c_rf / 2 | beta / sqrt(pi); the kernel has q' = qscale q_raw
         // and multiplies the sum by escale at the end
+        // LJ-PME: cl = ewaldcoeff_lj in scaled units
+        const double cl = (double)nb->ewaldcoeff_lj / b;
+        a.k.lje2        = (float)(cl * cl);
+        a.k.lje2_nlog2e = (float)(-cl * cl * 1.4426950408889634);
+        a.k.lje6_6      = (float)(std::pow(cl, 6) / 6.0);
+        a.k.lje_sh6     = (float)((double)nb->sh_lj_ewald / std::pow(b, 6) / 6.0);
+        a.k.tab_scale   = (float)((double)nb->tab_scale / b);
+        a.k.tab_max     = (float)(nb->tab_size - 2);
         const double cself = ew ? (double)nb->beta * 0.5641895835477563 : 0.5 * (double)nb->c_rf;
         a.k.two_k_rf = 2 * nb->k_rf;
         a.k.c_rf     = nb->c_rf;
@@ -636,6 +710,41 @@ int nbnxn_hip_set_vdw_modifier_flat(nbnxn_hip_ptr_t nb, int vdw_modifier, float 
     return 0;
 }
 
+int nbnxn_hip_set_ljpme_flat(nbnxn_hip_ptr_t nb, int comb_rule, float ewaldcoeff_lj, float sh_lj_ewald, const float *nbfp_comb)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->have_const) { return nbx_fail("set_ljpme before init_const"); }
+    if (comb_rule != NBX_LJCR_GEOM && comb_rule != NBX_LJCR_LB) { return nbx_fail("LJ-PME needs the geometric or the Lorentz-Berthelot combination rule, got %d", comb_rule); }
+    if (!(ewaldcoeff_lj > 0) || !nbfp_comb) { return nbx_fail("LJ-PME needs ewaldcoeff_lj > 0 and the per-type combination parameters"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    // grid C6 of every type pair, in float and in the reference's operation order
+    // (nbnxn_cuda_kernel_utils.cuh:202, :276-283): the combination rule is spent here, the kernel only reads the table
+    const int          nt = nb->ntype;
+    std::vector<float> g((size_t)nt * nt);
+    for (int i = 0; i < nt; i++)
+    {
+        for (int j = 0; j < nt; j++)
+        {
+            if (comb_rule == NBX_LJCR_GEOM) { g[(size_t)i * nt + j] = nbfp_comb[2 * i] * nbfp_comb[2 * j]; }
+            else
+            {
+                const float sigma  = nbfp_comb[2 * i] + nbfp_comb[2 * j];
+                const float eps    = nbfp_comb[2 * i + 1] * nbfp_comb[2 * j + 1];
+                const float sigma2 = sigma * sigma;
+                g[(size_t)i * nt + j] = eps * sigma2 * sigma2 * sigma2;
+            }
+        }
+    }
+    if (dev_reserve(nb->c6grid, g.size())) { return 1; }
+    HIP_TRY(hipMemcpyAsync(nb->c6grid.p, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, nb->stream[0]));
+    HIP_TRY(hipStreamSynchronize(nb->stream[0]));
+    nb->vdw_mod       = 3;
+    nb->rvdw_switch   = 0;
+    nb->ewaldcoeff_lj = ewaldcoeff_lj;
+    nb->sh_lj_ewald   = sh_lj_ewald;
+    return 0;
+}
+
 int nbnxn_hip_init_const(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic, const nbx_verlet_group_t *nbv_group)
 {
     if (check_handle(nb)) { return 1; }
@@ -643,17 +752,29 @@ int nbnxn_hip_init_const(nbnxn_hip_ptr_t nb, const nbx_interaction_const_t *ic, 
     const nbx_atomdata_t *nbat = nbv_group[0].nbat;
     int                   el;
     // flavour choice of nbnxn_cuda_data_mgmt.cu:303-357, reduced to what is built here
-    if (ic->vdwtype != NBX_VDW_CUT)
+    if (ic->vdwtype != NBX_VDW_CUT && ic->vdwtype != NBX_VDW_PME)
     {
-        return nbx_fail("VdW type %d is not built (cut-off LJ with the shift / switch modifiers is; LJ-PME is not)", ic->vdwtype);
+        return nbx_fail("The requested VdW type %d is not implemented in the HIP GPU accelerated kernels!", ic->vdwtype);
     }
     if (ic->eeltype == NBX_EEL_CUT || ic->eeltype == NBX_EEL_RF || ic->eeltype == NBX_EEL_GRF) { el = NBX_EL_RF; }
-    else if (ic->eeltype == NBX_EEL_PME || ic->eeltype == NBX_EEL_EWALD) { el = NBX_EL_EWALD_ANA; }
+    else if (ic->eeltype == NBX_EEL_PME || ic->eeltype == NBX_EEL_EWALD)
+    {
+        // pick_ewald_kernel_type (nbnxn_cuda_data_mgmt.cu:217-265): analytical unless the tabulated
+        // flavour is forced through the environment
+        const bool force_ana = getenv("GMX_HIP_NB_ANA_EWALD") != nullptr, force_tab = getenv("GMX_HIP_NB_TAB_EWALD") != nullptr;
+        if (force_ana && force_tab) { return nbx_fail("Both analytical and tabulated Ewald HIP non-bonded kernels requested through environment variables."); }
+        el = force_tab ? NBX_EL_EWALD_TAB : NBX_EL_EWALD_ANA;
+    }
     else { return nbx_fail("The requested electrostatics type %d is not implemented in the HIP GPU accelerated kernels!", ic->eeltype); }
     // eelCUT runs the RF kernel with k_rf = 0, c_rf = 1/rc as the reference sets them (forcerec.c:2072-2079)
     if (nbnxn_hip_init_const_flat(nb, el, ic->rcoulomb, ic->rvdw, ic->rlist, ic->epsfac, ic->k_rf, ic->c_rf,
                                   ic->ewaldcoeff_q, ic->sh_ewald, ic->dispersion_shift.cpot, ic->repulsion_shift.cpot,
                                   nbat->ntype, nbat->nbfp)) { return 1; }
+    if (ic->vdwtype == NBX_VDW_PME)
+    {
+        if (nbat->comb_rule != ic->ljpme_comb_rule) { return nbx_fail("LJ-PME combination rule %d differs from the atom data's (%d)", ic->ljpme_comb_rule, nbat->comb_rule); }
+        return nbnxn_hip_set_ljpme_flat(nb, ic->ljpme_comb_rule, ic->ewaldcoeff_lj, ic->sh_lj_ewald, nbat->nbfp_comb);
+    }
     return nbnxn_hip_set_vdw_modifier_flat(nb, ic->vdw_modifier, ic->rvdw_switch, ic->dispersion_shift.c2, ic->dispersion_shift.c3,
                                            ic->repulsion_shift.c2, ic->repulsion_shift.c3, ic->vdw_switch.c3, ic->vdw_switch.c4,
                                            ic->vdw_switch.c5);
@@ -854,6 +975,23 @@ int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, vo
     if (d_xq) { *d_xq = nb->xq.p; }
     if (d_f) { *d_f = nb->f.p; }
     if (d_type) { *d_type = nb->type.p; }
+    return 0;
+}
+
+int nbnxn_hip_download_coulomb_tab(nbnxn_hip_ptr_t nb, float *tab, int tab_alloc, int *tab_size, float *tab_scale)
+{
+    if (check_handle(nb)) { return 1; }
+    if (nb->el_type != NBX_EL_EWALD_TAB || !nb->coulomb_tab.p) { return nbx_fail("no Ewald force table: the flavour in use is not NBX_EL_EWALD_TAB"); }
+    if (tab_size) { *tab_size = nb->tab_size; }
+    if (tab_scale) { *tab_scale = nb->tab_scale; }
+    if (tab)
+    {
+        if (tab_alloc < nb->tab_size) { return nbx_fail("download_coulomb_tab: room for %d entries, table has %d", tab_alloc, nb->tab_size); }
+        HIP_TRY(hipSetDevice(nb->device));
+        HIP_TRY(hipMemcpy(tab, nb->coulomb_tab.p, nb->tab_size * sizeof(float), hipMemcpyDeviceToHost));
+        // undo the kernel's unit scaling (exact to half an ulp; the comparison with the reference table allows for it)
+        for (int i = 0; i < nb->tab_size; i++) { tab[i] = (float)((double)tab[i] * (double)nb->beta * (double)nb->beta); }
+    }
     return 0;
 }
 

@@ -40,6 +40,14 @@ struct nbx_kernel_k_t {
     float self;        // coefficient of q_i'^2 (scaled charges) in the scaled self energy
     float two_k_rf;    // reaction field: 2 k_rf
     float c_rf;        // reaction field: c_rf
+    // LJ-PME grid part (nbnxn_cuda_kernel_utils.cuh:186-302), scaled units: with cl = ewaldcoeff_lj / beta
+    float lje2;        // cl^2
+    float lje2_nlog2e; // -cl^2 log2(e): exp(-cl^2 r'^2) = exp2(r'^2 * lje2_nlog2e)
+    float lje6_6;      // cl^6 / 6
+    float lje_sh6;     // sh_lj_ewald / beta^6 / 6
+    // tabulated Ewald (nbnxn_cuda_kernel_utils.cuh:304-317): table index = r' * tab_scale
+    float tab_scale;   // coulomb_tab_scale / beta
+    float tab_max;     // table size - 2, as float: clamp of the interpolation index
 };
 
 // Everything a launch needs (the reference passes cu_atomdata_t / cu_nbparam_t / cu_plist_t
@@ -53,6 +61,8 @@ struct nbx_kernel_args_t {
     int           ntype;
     // parameters (cu_nbparam_t, :142-185)
     const float2  *nbfp;
+    const float   *c6grid;      // LJ-PME: grid C6 per type pair [ntype][ntype] (6*C6 convention), else null
+    const float   *coulomb_tab; // tabulated Ewald: force table / beta^2, else null
     nbx_kernel_k_t k;
     // pair list (cu_plist_t, :188-204)
     const nbx_sci_t  *sci;
@@ -65,9 +75,15 @@ struct nbx_kernel_args_t {
     int     zero_n4;
 };
 
-// vdw_mod: 0 plain cut-off (with or without potential shift), 1 force switch, 2 potential switch
+// el_type: NBX_EL_*; vdw_mod: 0 plain cut-off (with or without potential shift), 1 force switch,
+// 2 potential switch, 3 LJ-PME (either combination rule: the rule only shapes the c6grid table)
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune, bool vdw_cutoff,
                                 int vdw_mod, hipStream_t stream);
+
+// one translation unit per electrostatics flavour (nbnxn_kernel.hip compiled with -DNBX_UNIT_EL=n)
+hipError_t nbx_launch_nonbonded_rf(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream);
+hipError_t nbx_launch_nonbonded_ewald_ana(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream);
+hipError_t nbx_launch_nonbonded_ewald_tab(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream);
 
 // nbnxn_atomdata.hip
 hipError_t nbx_launch_gather_x(const int *a, const float *x, float4 *xq, int begin, int n, hipStream_t stream);

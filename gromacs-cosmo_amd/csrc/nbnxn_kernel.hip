@@ -32,12 +32,13 @@ namespace {
         const float *__restrict__ p_shift_vec, const float2 *__restrict__ p_nbfp,                   \
         const nbx_sci_t *__restrict__ p_sci, nbx_cj4_t *__restrict__ p_cj4,                         \
         const nbx_excl_t *__restrict__ p_excl, float *__restrict__ p_out, const int p_ntype,        \
-        float4 *__restrict__ p_zero, const int p_zero_n4, const nbx_kernel_k_t p_k
+        float4 *__restrict__ p_zero, const int p_zero_n4, const float *__restrict__ p_c6grid,       \
+        const float *__restrict__ p_tab, const nbx_kernel_k_t p_k
 #define NBX_KERNEL_ARGS_FROM_PARAMS                                                                \
-    const nbx_kernel_view_t a = {p_xq, p_f, p_type, p_shift_vec, p_ntype, p_nbfp, p_sci, p_cj4, p_excl, p_out, p_k};
+    const nbx_kernel_view_t a = {p_xq, p_f, p_type, p_shift_vec, p_ntype, p_nbfp, p_sci, p_cj4, p_excl, p_out, p_c6grid, p_tab, p_k};
 #define NBX_KERNEL_CALL_ARGS(A)                                                                    \
     (A).xq, (A).f, (A).type, (A).shift_vec, (A).nbfp, (A).sci, (A).cj4, (A).excl, (A).out, (A).ntype, (A).zero,   \
-        (A).zero_n4, (A).k
+        (A).zero_n4, (A).c6grid, (A).coulomb_tab, (A).k
 
 // device-side view with the same member names as nbx_kernel_args_t
 struct nbx_kernel_view_t {
@@ -51,6 +52,8 @@ struct nbx_kernel_view_t {
     nbx_cj4_t *__restrict__        cj4;
     const nbx_excl_t *__restrict__ excl;
     float *__restrict__            out;
+    const float *__restrict__      c6grid;
+    const float *__restrict__      tab;
     nbx_kernel_k_t                 k;
 };
 
@@ -161,6 +164,9 @@ __device__ __forceinline__ float wave_sum(float v)
 
 constexpr int MAX_LDS_TYPES = NBX_KERNEL_MAX_LDS_TYPES;
 
+// bytes per type pair in the LDS parameter table: {c6, c12} or, for LJ-PME, {c6, c12, c6grid, -}
+constexpr int lds_entry_bytes(int vmod) { return vmod == 3 ? 16 : 8; }
+
 // j-forces are not sent to memory one cluster at a time: on CDNA the wave's loads, stores
 // and atomics retire in order through one counter (vmcnt), so a load issued after an atomic
 // cannot be waited for without also waiting for that atomic's round trip to the memory side
@@ -207,7 +213,7 @@ __device__ __forceinline__ float and_mask(const float v, const int m)
 
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
 __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
-                                        const float2 c, const unsigned wexcl, const int bitpos, const bool allowed,
+                                        const float2 c, const float c6g, const unsigned wexcl, const int bitpos, const bool allowed,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
                                         float &E_lj, float &E_el, bool &any_in_rlist)
 {
@@ -236,6 +242,29 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
             // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6
             const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
             elj = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
+        }
+    }
+    else if (VMOD == 3)
+    {
+        // LJ-PME: the mesh part of the dispersion is taken off the pair force; like the Ewald
+        // correction it also acts between excluded pairs (nbnxn_cuda_kernel_utils.cuh:186-302,
+        // nbnxn_kernel_ref_inner.h:207-251).  c6g is the grid C6 of the type pair.
+        const float cr2  = r2 * a.k.lje2;
+        const float ex   = __builtin_amdgcn_exp2f(r2 * a.k.lje2_nlog2e);
+        const float poly = fmaf(fmaf(0.5f, cr2, 1.0f), cr2, 1.0f);
+        const float g    = c6g * fmaf(-ex, fmaf(inv_r6, poly, a.k.lje6_6), inv_r6);   // grid force * r
+        if (VDWC)
+        {
+            const float ljv = vdw_in_range ? and_mask(lj6, m) + g : 0.0f;
+            t = (and_mask(qq * inv_r, m) + ljv) * inv_r2;
+        }
+        else { t = (and_mask(fmaf(qq, inv_r, lj6), m) + g) * inv_r2; }
+        if (ENER)
+        {
+            // the shift sh_lj_ewald only goes with real LJ pairs
+            const float shift = fmaf(c.y, a.k.rep12, fmaf(c.x, a.k.ndisp6, c6g * a.k.lje_sh6));
+            elj = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m)
+                + c6g * (1.0f / 6.0f) * inv_r6 * fmaf(-ex, poly, 1.0f);
         }
     }
     else
@@ -273,6 +302,21 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     if (VDWC && ENER) { elj = vdw_in_range ? elj : 0.0f; }
     float F, gv = 0.0f;
     if (EL == NBX_EL_RF) { F = fmaf(qq, -a.k.two_k_rf, t); }
+    else if (EL == NBX_EL_EWALD_TAB)
+    {
+        // force table with linear interpolation (nbnxn_cuda_kernel_utils.cuh:304-317); the table
+        // was divided by beta^2 at upload and is indexed by the scaled distance.  The index is
+        // clamped: pairs beyond the cut-off (and the r = 0 self pair, NaN -> last entry) are
+        // discarded below but must not read outside the table.  Energies stay analytical, as
+        // in the reference (nbnxn_cuda_kernel.cuh:468-471).
+        const float rs  = fminf(r2 * inv_r * a.k.tab_scale, a.k.tab_max);
+        const int   idx = (int)rs;
+        const float fr  = rs - (float)idx;
+        const float t0  = a.tab[idx], t1 = a.tab[idx + 1];
+        const float T   = fmaf(fr, t1, fmaf(-fr, t0, t0));
+        if (ENER) { float unused; pme_corr_fv(r2, unused, gv); }
+        F = fmaf(qq, -T * inv_r, t);
+    }
     else
     {
         float gf;
@@ -338,14 +382,17 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
     float2 c[8];
+    float  cg[8];
+    constexpr int TS = lds_entry_bytes(VMOD);
     if (NBFP_LDS)
     {
-        const char *row = reinterpret_cast<const char *>(s_nbfp) + s.t * (MAX_LDS_TYPES * 8);
+        const char *row = reinterpret_cast<const char *>(s_nbfp) + s.t * (MAX_LDS_TYPES * TS);
 #pragma unroll
         for (int i = 0; i < 8; i++)
         {
             const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
-            c[i] = *reinterpret_cast<const float2 *>(row + tb);
+            c[i]  = *reinterpret_cast<const float2 *>(row + tb);
+            cg[i] = VMOD == 3 ? *reinterpret_cast<const float *>(row + tb + 8) : 0.0f;
         }
     }
     else
@@ -354,8 +401,9 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         for (int i = 0; i < 8; i++)
         {
             const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
-            c[i] = a.nbfp[tb * a.ntype + s.t];
-            if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; }
+            c[i]  = a.nbfp[tb * a.ntype + s.t];
+            cg[i] = VMOD == 3 ? a.c6grid[tb * a.ntype + s.t] : 0.0f;
+            if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; cg[i] *= a.k.c6scale; }
         }
     }
     float4 xj = s.x;
@@ -370,7 +418,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
+            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
@@ -398,7 +446,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     __shared__ int    s_ti[64];
     __shared__ float  s_red[192];
     // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
-    __shared__ float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES : 1];
+    constexpr int     TS = lds_entry_bytes(VMOD);
+    __shared__ __attribute__((aligned(16))) float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES * (TS / 8) : 1];
     constexpr int     FJ_CAP = 32;
     __shared__ float  s_fj[FJ_CAP * 24];
     __shared__ int    s_fjc[FJ_CAP];
@@ -436,7 +485,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
                 const int t_i = k / ntype, t_j = k - t_i * ntype;
                 float2    c   = a.nbfp[k];
                 if (EL != NBX_EL_RF) { c.x *= a.k.c6scale; c.y *= a.k.c12scale; }
-                s_nbfp[t_j * MAX_LDS_TYPES + t_i] = c;
+                char *entry = reinterpret_cast<char *>(s_nbfp) + (t_j * MAX_LDS_TYPES + t_i) * TS;
+                *reinterpret_cast<float2 *>(entry) = c;
+                if (VMOD == 3) { *reinterpret_cast<float *>(entry + 8) = a.c6grid[k] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
             }
         }
     }
@@ -465,7 +516,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         {
             xi[i].x = (xi[i].x - ox) * a.k.xscale; xi[i].y = (xi[i].y - oy) * a.k.xscale; xi[i].z = (xi[i].z - oz) * a.k.xscale;
         }
-        const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? 8u : 1u);
+        const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? (unsigned)TS : 1u);
         if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
         fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
     }
@@ -478,6 +529,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
             // self term (nbnxn_cuda_kernel.cuh:239-262) in the scaled charges
             const float q = s_xqi[lane].w;
             E_el = a.k.self * q * q;
+            if (VMOD == 3)
+            {
+                // LJ-PME self term: 0.5 * C6_ii / 6 * cl^6 / 6 per atom (nbnxn_cuda_kernel.cuh:232-246)
+                const int ti = s_ti[lane];
+                float     c6ii;
+                if (NBFP_LDS) { c6ii = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_nbfp) + (ti * MAX_LDS_TYPES + ti) * TS); }
+                else { c6ii = a.nbfp[ti * ntype + ti].x * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
+                E_lj = c6ii * (0.5f / 6.0f) * a.k.lje6_6;
+            }
         }
     }
 
@@ -593,18 +653,44 @@ void launch_vmod(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, in
 {
     if (vdw_mod == 1) { launch_ener_prune<EL, VDWC, 1>(a, nsci, ener, prune, stream); }
     else if (vdw_mod == 2) { launch_ener_prune<EL, VDWC, 2>(a, nsci, ener, prune, stream); }
+    else if (vdw_mod == 3) { launch_ener_prune<EL, VDWC, 3>(a, nsci, ener, prune, stream); }
     else { launch_ener_prune<EL, VDWC, 0>(a, nsci, ener, prune, stream); }
 }
 
 } // namespace
 
+// One translation unit per electrostatics flavour (Makefile: -DNBX_UNIT_EL=0|1|2), so that the
+// flavour table (nbnxn_cuda_kernels.cuh has 6 x 5 x 4 entries) builds in parallel.
+#if NBX_UNIT_EL == 0
+hipError_t nbx_launch_nonbonded_rf(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool, int vdw_mod, hipStream_t stream)
+{
+    // no twin-range flavour for reaction field: rvdw == rcoulomb there (PME load balancing scales rcoulomb only)
+    launch_vmod<NBX_EL_RF, false>(a, nsci, ener, prune, vdw_mod, stream);
+    return hipGetLastError();
+}
+
 hipError_t nbx_launch_nonbonded(const nbx_kernel_args_t &a, int nsci, int el_type, bool ener, bool prune, bool vdw_cutoff,
                                 int vdw_mod, hipStream_t stream)
 {
     if (nsci <= 0) { return hipSuccess; }
-    // the twin-range flavour exists for Ewald only (PME load balancing scales rcoulomb, not rvdw)
-    if (el_type == NBX_EL_RF) { launch_vmod<NBX_EL_RF, false>(a, nsci, ener, prune, vdw_mod, stream); }
-    else if (vdw_cutoff) { launch_vmod<NBX_EL_EWALD_ANA, true>(a, nsci, ener, prune, vdw_mod, stream); }
+    if (el_type == NBX_EL_RF) { return nbx_launch_nonbonded_rf(a, nsci, ener, prune, vdw_cutoff, vdw_mod, stream); }
+    if (el_type == NBX_EL_EWALD_TAB) { return nbx_launch_nonbonded_ewald_tab(a, nsci, ener, prune, vdw_cutoff, vdw_mod, stream); }
+    return nbx_launch_nonbonded_ewald_ana(a, nsci, ener, prune, vdw_cutoff, vdw_mod, stream);
+}
+#elif NBX_UNIT_EL == 1
+hipError_t nbx_launch_nonbonded_ewald_ana(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream)
+{
+    if (vdw_cutoff) { launch_vmod<NBX_EL_EWALD_ANA, true>(a, nsci, ener, prune, vdw_mod, stream); }
     else { launch_vmod<NBX_EL_EWALD_ANA, false>(a, nsci, ener, prune, vdw_mod, stream); }
     return hipGetLastError();
 }
+#elif NBX_UNIT_EL == 2
+hipError_t nbx_launch_nonbonded_ewald_tab(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream)
+{
+    if (vdw_cutoff) { launch_vmod<NBX_EL_EWALD_TAB, true>(a, nsci, ener, prune, vdw_mod, stream); }
+    else { launch_vmod<NBX_EL_EWALD_TAB, false>(a, nsci, ener, prune, vdw_mod, stream); }
+    return hipGetLastError();
+}
+#else
+#error "NBX_UNIT_EL must be 0 (reaction field), 1 (analytical Ewald) or 2 (tabulated Ewald)"
+#endif

@@ -89,6 +89,8 @@ def load():
     lib.nbnxn_hip_last_kernel_ms.restype = cf
     lib.nbnxn_hip_set_prune.argtypes = [vp, ci, ci]
     lib.nbnxn_hip_set_vdw_modifier_flat.argtypes = [vp, ci] + [cf] * 8
+    lib.nbnxn_hip_set_ljpme_flat.argtypes = [vp, ci, cf, cf, vp]
+    lib.nbnxn_hip_download_coulomb_tab.argtypes = [vp, vp, ci, C.POINTER(ci), C.POINTER(cf)]
     lib.nbnxn_hip_set_atom_order.argtypes = [vp, ci, vp, vp]
     lib.nbnxn_hip_upload_xq_flat.argtypes = [vp, vp, ci]
     lib.nbnxn_hip_copy_x_to_xq.argtypes = [vp, vp, ci, ci]
@@ -144,6 +146,19 @@ class NbnxnHip:
                                                      ip.disp_cpot, ip.rep_cpot, ntype, abi.ptr(nbfp)))
         self._chk(self.lib.nbnxn_hip_set_vdw_modifier_flat(self.h, ip.vdw_modifier, ip.rvdw_switch, ip.disp_c2, ip.disp_c3,
                                                            ip.rep_c2, ip.rep_c3, ip.sw_c3, ip.sw_c4, ip.sw_c5))
+        if ip.vdwtype == abi.VDW_PME:
+            from .system import nbfp_comb
+            comb = nbfp_comb(nbfp, ntype, ip.ljpme_comb_rule)
+            self._chk(self.lib.nbnxn_hip_set_ljpme_flat(self.h, ip.ljpme_comb_rule, ip.ewaldcoeff_lj, ip.sh_lj_ewald,
+                                                        abi.ptr(comb)))
+
+    def coulomb_tab(self):
+        """(table [size] float32, scale) of the tabulated Ewald flavour, in the reference's units."""
+        n, sc = C.c_int(0), C.c_float(0)
+        self._chk(self.lib.nbnxn_hip_download_coulomb_tab(self.h, None, 0, C.byref(n), C.byref(sc)))
+        tab = np.zeros(n.value, dtype=np.float32)
+        self._chk(self.lib.nbnxn_hip_download_coulomb_tab(self.h, abi.ptr(tab), n.value, C.byref(n), C.byref(sc)))
+        return tab, sc.value
 
     def init_const_struct(self, ic, nbv_group):
         self._chk(self.lib.nbnxn_hip_init_const(self.h, C.byref(ic), C.byref(nbv_group)))

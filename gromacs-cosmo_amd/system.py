@@ -73,10 +73,19 @@ class InteractionParams:
     sw_c3: float = 0.0
     sw_c4: float = 0.0
     sw_c5: float = 0.0
+    # LJ-PME (ic->vdwtype == evdwPME): combination rule of the mesh part, its Ewald coefficient
+    # and the potential shift of forcerec.c:2012-2018
+    vdwtype: int = abi.VDW_CUT
+    ljpme_comb_rule: int = abi.LJCR_GEOM
+    ewaldcoeff_lj: float = 0.0
+    sh_lj_ewald: float = 0.0
 
     def to_struct(self):
         ic = abi.InteractionConst()
-        ic.vdwtype = abi.VDW_CUT
+        ic.vdwtype = self.vdwtype
+        ic.ljpme_comb_rule = self.ljpme_comb_rule
+        ic.ewaldcoeff_lj = self.ewaldcoeff_lj
+        ic.sh_lj_ewald = self.sh_lj_ewald
         ic.vdw_modifier = self.vdw_modifier
         ic.rvdw = self.rvdw
         ic.rvdw_switch = self.rvdw_switch
@@ -124,6 +133,56 @@ def with_potential_switch(ip, rvdw_switch):
     d = ip.rvdw - rvdw_switch
     return dataclasses.replace(ip, vdw_modifier=abi.MOD_POTSWITCH, rvdw_switch=rvdw_switch, disp_cpot=0.0, rep_cpot=0.0,
                                sw_c3=-10 * d ** -3, sw_c4=15 * d ** -4, sw_c5=-6 * d ** -5)
+
+
+def calc_ewaldcoeff_lj(rc, rtol):
+    """gmxlib/ewald_util.c:86-129: bisection on exp(-x^2)(1 + x^2 + x^4/2) = rtol, x = beta_lj*rc."""
+    fn = lambda x: math.exp(-(x * rc) ** 2) * (1 + (x * rc) ** 2 + (x * rc) ** 4 / 2.0)
+    x, i = 5.0, 0
+    while True:
+        i += 1
+        x *= 2
+        if fn(x) <= rtol:
+            break
+    lo, hi = 0.0, x
+    for _ in range(i + 60):
+        x = 0.5 * (lo + hi)
+        if fn(x) > rtol:
+            lo = x
+        else:
+            hi = x
+    return x
+
+
+def with_ljpme(ip, comb_rule=abi.LJCR_GEOM, rtol_lj=1e-3):
+    """vdwtype = PME with potential shift (forcerec.c:2000-2018): ewaldcoeff_lj from ewald_rtol_lj
+    (forcerec.c:2803), sh_lj_ewald = (exp(-x)(1 + x + x^2/2) - 1) / rvdw^6 with x = (beta_lj rvdw)^2."""
+    import dataclasses
+    b = calc_ewaldcoeff_lj(ip.rvdw, rtol_lj)
+    crc2 = (b * ip.rvdw) ** 2
+    sh = (math.exp(-crc2) * (1 + crc2 + 0.5 * crc2 * crc2) - 1) * ip.rvdw ** -6
+    return dataclasses.replace(ip, vdwtype=abi.VDW_PME, ljpme_comb_rule=comb_rule, ewaldcoeff_lj=b, sh_lj_ewald=sh)
+
+
+def nbfp_comb(nbfp, ntype, comb_rule):
+    """Per-type combination parameters from the diagonal of the 6*C6 / 12*C12 table, as
+    nbnxn_atomdata.c:397-429 fills nbat->nbfp_comb (float results of double arithmetic)."""
+    t = np.asarray(nbfp, dtype=np.float32).reshape(ntype, ntype, 2)
+    out = np.zeros((ntype, 2), dtype=np.float32)
+    for i in range(ntype):
+        c6, c12 = float(t[i, i, 0]), float(t[i, i, 1])
+        if comb_rule == abi.LJCR_GEOM:
+            out[i] = math.sqrt(c6), math.sqrt(c12)
+        elif c6 > 0 and c12 > 0:
+            out[i] = 0.5 * (c12 / c6) ** (1.0 / 6.0), math.sqrt(c6 * c6 / c12)
+    return out
+
+
+def with_tabulated_ewald(ip):
+    """The reference's tabulated-force Ewald flavour (eelCuEWALD_TAB, GMX_CUDA_NB_TAB_EWALD)."""
+    import dataclasses
+    assert ip.el_type != abi.EL_RF
+    return dataclasses.replace(ip, el_type=abi.EL_EWALD_TAB)
 
 
 def calc_ewaldcoeff_q(rc, rtol):

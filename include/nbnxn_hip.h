@@ -45,12 +45,13 @@ enum { NBX_LOCAL = 0, NBX_NONLOCAL = 1 };
 
 /* eeltype / vdwtype / modifier values this module accepts (types/enums.h:92-122) */
 enum { NBX_EEL_CUT = 0, NBX_EEL_RF = 1, NBX_EEL_GRF = 2, NBX_EEL_PME = 3, NBX_EEL_EWALD = 4 };
-enum { NBX_VDW_CUT = 0 };
+enum { NBX_VDW_CUT = 0, NBX_VDW_PME = 5 };
+enum { NBX_LJCR_GEOM = 0, NBX_LJCR_LB = 1, NBX_LJCR_NONE = 2 };   /* ljcr*, types/nbnxn_pairlist.h; = eljpme* */
 enum { NBX_MOD_POTSHIFT_VERLET = 0, NBX_MOD_POTSHIFT = 1, NBX_MOD_NONE = 2, NBX_MOD_POTSWITCH = 3,
        NBX_MOD_EXACTCUTOFF = 4, NBX_MOD_FORCESWITCH = 5 };   /* enum eintmod, types/enums.h:92-93 */
 
 /* electrostatics flavour of the device kernel (nbnxn_cuda/nbnxn_cuda_types.h:80-82) */
-enum { NBX_EL_RF = 0, NBX_EL_EWALD_ANA = 1, NBX_EL_NR };
+enum { NBX_EL_RF = 0, NBX_EL_EWALD_ANA = 1, NBX_EL_EWALD_TAB = 2, NBX_EL_NR };
 
 /* ------------------------------------------------------------------------------------
  * ABI structs.  Each is layout-identical to the named reference struct so that the
@@ -343,7 +344,8 @@ int nbnxn_hip_wait_gpu(nbnxn_hip_ptr_t nb, const nbx_atomdata_t *nbat, int flags
  * ---------------------------------------------------------------------------------- */
 
 /* = nbnxn_hip_init_const.  nbfp is [ntype*ntype*2] (6*C6, 12*C12 pairs,
- * mdlib/nbnxn_atomdata.c:611-617); el_type is NBX_EL_RF or NBX_EL_EWALD_ANA. */
+ * mdlib/nbnxn_atomdata.c:611-617); el_type is NBX_EL_RF, NBX_EL_EWALD_ANA or NBX_EL_EWALD_TAB
+ * (the reference's tabulated-force flavour, eelCuEWALD_TAB: nbnxn_cuda_types.h:80-82). */
 int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type,
                               float rcoulomb, float rvdw, float rlist,
                               float epsfac, float k_rf, float c_rf,
@@ -359,6 +361,14 @@ int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type,
 int nbnxn_hip_set_vdw_modifier_flat(nbnxn_hip_ptr_t nb, int vdw_modifier, float rvdw_switch,
                                     float disp_c2, float disp_c3, float rep_c2, float rep_c3,
                                     float sw_c3, float sw_c4, float sw_c5);
+
+/* LJ-PME (ic->vdwtype == evdwPME) for hosts that use init_const_flat; the struct-taking
+ * nbnxn_hip_init_const reads the same from ic and nbat (nbnxn_cuda_data_mgmt.cu:281-282, 322-334,
+ * 367-378).  comb_rule is NBX_LJCR_GEOM or NBX_LJCR_LB (ic->ljpme_comb_rule), nbfp_comb the 2*ntype
+ * per-type combination parameters of nbat->nbfp_comb (nbnxn_atomdata.c:397-429).  Replaces any LJ
+ * modifier set before: the reference has no switched LJ-PME flavour.  Call after init_const_flat. */
+int nbnxn_hip_set_ljpme_flat(nbnxn_hip_ptr_t nb, int comb_rule, float ewaldcoeff_lj, float sh_lj_ewald,
+                             const float *nbfp_comb);
 
 int nbnxn_hip_init_pairlist_flat(nbnxn_hip_ptr_t nb, int iloc, float rlist,
                                  int nsci, const nbx_sci_t *sci,
@@ -397,6 +407,12 @@ int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, vo
  * slot (entry index mod nslots), read_outputs / wait_gpu sum the slots in double.  For
  * resident callers that reduce them on the device (the multi-GPU all-reduce). */
 int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, int *stride);
+
+/* Verification aid for the tabulated Ewald flavour: size and scale of the force table this
+ * module generated (init_ewald_coulomb_force_table, nbnxn_cuda_data_mgmt.cu:120-183:
+ * 1536 points, scale = (size - 2) / rcoulomb) and, when tab != NULL, its entries in the
+ * reference's units. */
+int nbnxn_hip_download_coulomb_tab(nbnxn_hip_ptr_t nb, float *tab, int tab_alloc, int *tab_size, float *tab_scale);
 
 /* the HIP stream (hipStream_t) of a locality, as an opaque pointer */
 void *nbnxn_hip_get_stream(nbnxn_hip_ptr_t nb, int iloc);

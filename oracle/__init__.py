@@ -20,7 +20,10 @@ class OracleParams(C.Structure):
                 ("disp_cpot", C.c_double), ("rep_cpot", C.c_double),
                 ("vdw_modifier", C.c_int), ("rvdw_switch", C.c_double),
                 ("disp_c2", C.c_double), ("disp_c3", C.c_double), ("rep_c2", C.c_double), ("rep_c3", C.c_double),
-                ("sw_c3", C.c_double), ("sw_c4", C.c_double), ("sw_c5", C.c_double)]
+                ("sw_c3", C.c_double), ("sw_c4", C.c_double), ("sw_c5", C.c_double),
+                ("ljpme", C.c_int), ("ewaldcoeff_lj", C.c_double), ("sh_lj_ewald", C.c_double),
+                ("nbfp_comb", C.c_void_p),
+                ("coul_tab", C.c_void_p), ("tab_size", C.c_int), ("tab_scale", C.c_double)]
 
 
 class RefParams(C.Structure):
@@ -31,15 +34,65 @@ class RefParams(C.Structure):
                 ("disp_cpot", C.c_float), ("rep_cpot", C.c_float),
                 ("vdw_modifier", C.c_int), ("rvdw_switch", C.c_float),
                 ("disp_c2", C.c_float), ("disp_c3", C.c_float), ("rep_c2", C.c_float), ("rep_c3", C.c_float),
-                ("sw_c3", C.c_float), ("sw_c4", C.c_float), ("sw_c5", C.c_float)]
+                ("sw_c3", C.c_float), ("sw_c4", C.c_float), ("sw_c5", C.c_float),
+                ("ljpme", C.c_int), ("ewaldcoeff_lj", C.c_float), ("sh_lj_ewald", C.c_float)]
 
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def oracle_params(ip):
-    """ip: gromacs_cosmo_amd.system.InteractionParams (float32-rounded like the C structs)."""
+GPU_EWALD_TAB_SIZE = 1536   # GPU_EWALD_COULOMB_FORCE_TABLE_SIZE
+
+
+def ewald_force_table(beta, rc, ntab=GPU_EWALD_TAB_SIZE):
+    """(table, scale) as the reference's GPU module makes them (nbnxn_cuda_data_mgmt.cu:120-183)."""
+    lib().oracle_ewald_force_table.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p]
+    scale = (ntab - 2) / float(np.float32(rc))
+    tab = np.zeros(ntab, dtype=np.float32)
+    lib().oracle_ewald_force_table(ntab, 1.0 / scale, float(np.float32(beta)), _p(tab))
+    return tab, scale
+
+
+def _ljpme_code(ip):
+    """0 off, 1 geometric, 2 Lorentz-Berthelot (oracle_params_t.ljpme)."""
+    if getattr(ip, "vdwtype", 0) != 5:
+        return 0
+    return 1 + int(ip.ljpme_comb_rule)
+
+
+def nbfp_comb(nbfp, ntype, ljpme):
+    """nbat->nbfp_comb from the diagonal of nbat->nbfp (nbnxn_atomdata.c:397-429): ljpme 1 ->
+    sqrt(6 C6), sqrt(12 C12); 2 -> 0.5 (C12'/C6')^(1/6), sqrt(C6'^2/C12') (0, 0 without LJ)."""
+    t = np.asarray(nbfp, dtype=np.float32).reshape(ntype, ntype, 2).astype(np.float64)
+    out = np.zeros((ntype, 2), dtype=np.float32)
+    for i in range(ntype):
+        c6, c12 = t[i, i]
+        if ljpme == 1:
+            out[i] = np.sqrt(c6), np.sqrt(c12)
+        elif c6 > 0 and c12 > 0:
+            out[i] = 0.5 * (c12 / c6) ** (1.0 / 6.0), np.sqrt(c6 * c6 / c12)
+    return out
+
+
+def oracle_params(ip, ntype=None, nbfp=None):
+    """ip: gromacs_cosmo_amd.system.InteractionParams (float32-rounded like the C structs).
+    LJ-PME needs the LJ table (for nbfp_comb); the arrays the struct points to are kept alive
+    on the returned object."""
+    p = _oracle_params_scalar(ip)
+    p.ljpme = _ljpme_code(ip)
+    if p.ljpme:
+        f = lambda v: float(np.float32(v))
+        p.ewaldcoeff_lj, p.sh_lj_ewald = f(ip.ewaldcoeff_lj), f(ip.sh_lj_ewald)
+        p._comb = nbfp_comb(nbfp, ntype, p.ljpme)
+        p.nbfp_comb = p._comb.ctypes.data
+    if ip.el_type == 2:
+        p._tab, sc = ewald_force_table(ip.ewaldcoeff_q, ip.rcoulomb)
+        p.coul_tab, p.tab_size, p.tab_scale = p._tab.ctypes.data, len(p._tab), sc
+    return p
+
+
+def _oracle_params_scalar(ip):
     f = lambda v: float(np.float32(v))
     return OracleParams(ip.el_type, f(ip.rcoulomb), f(ip.rvdw), f(ip.epsfac), f(ip.k_rf), f(ip.c_rf),
                         f(ip.ewaldcoeff_q), f(ip.sh_ewald), f(ip.disp_cpot), f(ip.rep_cpot),
@@ -55,7 +108,8 @@ def ref_params(ip):
                      int(getattr(ip, "vdw_modifier", 1)), getattr(ip, "rvdw_switch", 0.0),
                      getattr(ip, "disp_c2", 0.0), getattr(ip, "disp_c3", 0.0), getattr(ip, "rep_c2", 0.0),
                      getattr(ip, "rep_c3", 0.0), getattr(ip, "sw_c3", 0.0), getattr(ip, "sw_c4", 0.0),
-                     getattr(ip, "sw_c5", 0.0))
+                     getattr(ip, "sw_c5", 0.0), _ljpme_code(ip), getattr(ip, "ewaldcoeff_lj", 0.0),
+                     getattr(ip, "sh_lj_ewald", 0.0))
 
 
 _oracle = None
@@ -95,7 +149,7 @@ def kernel_gpu_list(xq, type_, ntype, nbfp, shift_vec, pl, ip, calc_ener=True):
     fshift = np.zeros((45, 3), dtype=np.float64)
     vc, vv = C.c_double(0), C.c_double(0)
     counts = (C.c_longlong * 3)()
-    p = oracle_params(ip)
+    p = oracle_params(ip, ntype, nbfp)
     nbfp = np.ascontiguousarray(nbfp, dtype=np.float32)
     rc = lib().oracle_kernel_gpu_list(C.c_int(n), _p(xq), _p(type_), C.c_int(ntype), _p(nbfp), _p(shift_vec),
                                       C.c_int(pl.nsci), _p(pl.sci), _p(pl.cj4), _p(pl.excl),
@@ -109,7 +163,7 @@ def kernel_gpu_list(xq, type_, ntype, nbfp, shift_vec, pl, ip, calc_ener=True):
 def kernel_gpu_list_f32(xq, type_, ntype, nbfp, shift_vec, pl, ip):
     n = len(xq)
     f = np.zeros((n, 3), dtype=np.float32)
-    p = oracle_params(ip)
+    p = oracle_params(ip, ntype, nbfp)
     nbfp = np.ascontiguousarray(nbfp, dtype=np.float32)
     lib().oracle_kernel_gpu_list_f32(C.c_int(n), _p(xq), _p(type_), C.c_int(ntype), _p(nbfp), _p(shift_vec),
                                      C.c_int(pl.nsci), _p(pl.sci), _p(pl.cj4), _p(pl.excl), C.byref(p), _p(f))
@@ -128,7 +182,7 @@ def brute_force(x, q, type_, ntype, nbfp, box, excl_index, excl_a, ip, calc_ener
     f = np.zeros((n, 3), dtype=np.float64)
     vir = np.zeros(9, dtype=np.float64)
     vc, vv = C.c_double(0), C.c_double(0)
-    p = oracle_params(ip)
+    p = oracle_params(ip, ntype, nbfp)
     x = np.ascontiguousarray(x, dtype=np.float32)
     q = np.ascontiguousarray(q, dtype=np.float32)
     type_ = np.ascontiguousarray(type_, dtype=np.int32)

@@ -47,14 +47,60 @@ typedef struct {
     double rvdw_switch;
     double disp_c2, disp_c3, rep_c2, rep_c3;
     double sw_c3, sw_c4, sw_c5;
+    /* LJ-PME (ic->vdwtype == evdwPME): ljpme 0 off, 1 geometric, 2 Lorentz-Berthelot grid;
+     * nbfp_comb as nbat->nbfp_comb (nbnxn_atomdata.c:397-429) */
+    int          ljpme;
+    double       ewaldcoeff_lj, sh_lj_ewald;
+    const float *nbfp_comb;
+    /* tabulated Ewald force (el_type NBX_EL_EWALD_TAB): the GPU flavour's table
+     * (nbnxn_cuda_data_mgmt.cu:120-183), linear interpolation (nbnxn_cuda_kernel_utils.cuh:304-317) */
+    const float *coul_tab;
+    int          tab_size;
+    double       tab_scale;
 } oracle_params_t;
+
+/* grid C6 of a type pair (nbnxn_kernel_ref_inner.h:211-226) */
+static double c6grid_of(const oracle_params_t *p, int ti, int tj)
+{
+    const float *ljc = p->nbfp_comb;
+    if (p->ljpme == 1) { return (double)ljc[ti * 2] * ljc[tj * 2]; }
+    {
+        const double sigma = (double)ljc[ti * 2] + ljc[tj * 2], eps = (double)ljc[ti * 2 + 1] * ljc[tj * 2 + 1];
+        const double s2 = sigma * sigma;
+        return eps * s2 * s2 * s2;
+    }
+}
+
+/* Ewald long-range force table as table_spline3_fill_ewald_lr makes it (tables.c:165-311),
+ * force column only, with the float roundings of the reference's real-typed table. */
+void oracle_ewald_force_table(int ntab, double dx, double beta, float *tab_f)
+{
+    int    i;
+    double dc;
+    for (i = ntab - 1; i >= 1; i--)
+    {
+        const double x0 = i * dx;
+        const double v0 = erf(beta * x0) / x0;
+        const double x1 = (i - 1) * dx;
+        const double v1 = i == 1 ? beta * 2 / sqrt(M_PI) : erf(beta * x1) / x1;
+        const double vm = erf(beta * (x0 - 0.5 * dx)) / (x0 - 0.5 * dx);
+        double       a2dx = (v0 + v1 - 2 * vm) / (0.25 * dx);          /* :247 */
+        dc = (v0 - v1) / dx + 0.5 * a2dx;                             /* :252 */
+        if (i == ntab - 1) { tab_f[i] = (float)(-dc); }               /* :255-264 */
+        else { tab_f[i] = (float)(tab_f[i] + -0.5 * dc); }
+        a2dx = (dc * dx + v1 - v0) * 2 / dx;                          /* :272-277 */
+        dc   = dc - a2dx;
+        tab_f[i - 1] = (float)(-0.5 * dc);                            /* :289 */
+    }
+    tab_f[0] *= 2;                                                    /* :292 */
+}
 
 /* Pair term shared by the list kernel and the brute-force sum.
  * dx = xi - xj (i already shifted).  int_bit = 1: interacting pair, 0: excluded pair that
  * still gets the reaction-field / Ewald-mesh correction (the reference's EXCL_FORCES).
  * Returns the scalar F/r; adds the pair energies when vc/vv are non-NULL. */
 static double pair_term(const oracle_params_t *p, double rsq, int int_bit,
-                        double qq /* epsfac*qi*qj */, double c6, double c12,
+                        double qq /* epsfac*qi*qj */, double c6, double c12, double c6grid,
                         double *vc, double *vv)
 {
     double rinv, rinvsq, rinvsix, fscal, r;
@@ -69,6 +115,17 @@ static double pair_term(const oracle_params_t *p, double rsq, int int_bit,
         /* kernel_gpu_ref.c:264-273, kernel_ref_inner.h:296-299 */
         fscal = qq * (int_bit * rinv * rinvsq - 2.0 * p->k_rf);
         if (vc) { *vc += qq * (int_bit * rinv + p->k_rf * rsq - p->c_rf); }
+    }
+    else if (p->el_type == NBX_EL_EWALD_TAB)
+    {
+        /* nbnxn_cuda_kernel.cuh:451-458 (force from the table), :468-471 (analytical energy) */
+        const double norm = p->tab_scale * r;
+        const int    idx  = (int)norm;
+        const double fr2  = norm - idx, fr1 = 1.0 - fr2;
+        const double br   = p->beta * r;
+        if (idx + 1 >= p->tab_size) { abort(); }
+        fscal = qq * (int_bit * rinvsq - (fr1 * p->coul_tab[idx] + fr2 * p->coul_tab[idx + 1])) * rinv;
+        if (vc) { *vc += qq * ((int_bit - erf(br)) * rinv - int_bit * p->sh_ewald); }
     }
     else
     {
@@ -110,6 +167,15 @@ static double pair_term(const oracle_params_t *p, double rsq, int int_bit,
             const double dsw = (3 * p->sw_c3 + (4 * p->sw_c4 + 5 * p->sw_c5 * rsw) * rsw) * rsw * rsw;
             frLJ = frLJ * sw - r * VLJ * dsw;
             VLJ *= sw;
+        }
+        if (p->ljpme)
+        {
+            /* kernel_ref_inner.h:207-251: mesh part of the dispersion, not masked by int_bit */
+            const double rinvsix_nm = rinvsq * rinvsq * rinvsq;
+            const double lje2 = p->ewaldcoeff_lj * p->ewaldcoeff_lj;
+            const double cr2 = lje2 * rsq, expmcr2 = exp(-cr2), poly = 1 + cr2 + 0.5 * cr2 * cr2;
+            frLJ += c6grid * (rinvsix_nm - expmcr2 * (rinvsix_nm * poly + lje2 * lje2 * lje2 / 6.0));
+            VLJ  += c6grid / 6 * (rinvsix_nm * (1 - expmcr2 * poly) + p->sh_lj_ewald * int_bit);
         }
         fscal += frLJ * rinvsq;
         if (vv) { *vv += VLJ; }
@@ -162,6 +228,16 @@ int oracle_kernel_gpu_list(int natoms, const float *xq, const int *type, int nty
             {
                 vctot += -p->epsfac * p->beta * (0.5 * M_2_SQRTPI) * q2;
             }
+            if (p->ljpme)
+            {
+                /* LJ-PME self term (kernel_ref_outer.h:318-321, nbnxn_cuda_kernel.cuh:232-246) */
+                const double l2 = p->ewaldcoeff_lj * p->ewaldcoeff_lj;
+                for (ic = 0; ic < NSC * CL; ic++)
+                {
+                    const int t = type[s * NSC * CL + ic];
+                    vvtot += 0.5 * nbfp[(size_t)t * (ntype + 1) * 2] / 6 * (l2 * l2 * l2 / 6.0);
+                }
+            }
         }
 
         for (j4 = e->cj4_ind_start; j4 < e->cj4_ind_end; j4++)
@@ -201,6 +277,7 @@ int oracle_kernel_gpu_list(int natoms, const float *xq, const int *type, int nty
                                 c6    = nbfp[(type[ia] * ntype + type[ja]) * 2];
                                 c12   = nbfp[(type[ia] * ntype + type[ja]) * 2 + 1];
                                 fscal = pair_term(p, rsq, int_bit, iq * xq[(size_t)ja * 4 + 3], c6, c12,
+                                                  p->ljpme ? c6grid_of(p, type[ia], type[ja]) : 0.0,
                                                   calc_ener ? &vctot : NULL, calc_ener ? &vvtot : NULL);
                                 fix += fscal * dx; fiy += fscal * dy; fiz += fscal * dz;
                                 f[(size_t)ja * 3]     -= fscal * dx;
@@ -307,6 +384,7 @@ int oracle_brute_force(int natoms, const float *x, const float *q, const int *ty
             c6    = nbfp[(type[i] * ntype + type[j]) * 2];
             c12   = nbfp[(type[i] * ntype + type[j]) * 2 + 1];
             fscal = pair_term(p, rsq, int_bit, p->epsfac * q[i] * q[j], c6, c12,
+                              p->ljpme ? c6grid_of(p, type[i], type[j]) : 0.0,
                               calc_ener ? Vc : NULL, calc_ener ? Vvdw : NULL);
             for (d = 0; d < 3; d++)
             {
@@ -323,6 +401,11 @@ int oracle_brute_force(int natoms, const float *x, const float *q, const int *ty
     {
         if (p->el_type == NBX_EL_RF) { *Vc += -p->epsfac * 0.5 * p->c_rf * q2; }
         else { *Vc += -p->epsfac * p->beta * (0.5 * M_2_SQRTPI) * q2; }
+        if (p->ljpme)
+        {
+            const double l2 = p->ewaldcoeff_lj * p->ewaldcoeff_lj;
+            for (i = 0; i < natoms; i++) { *Vvdw += 0.5 * nbfp[(size_t)type[i] * (ntype + 1) * 2] / 6 * (l2 * l2 * l2 / 6.0); }
+        }
     }
     return 0;
 }

@@ -123,12 +123,17 @@ typedef struct {
     float rvdw_switch;
     float disp_c2, disp_c3, rep_c2, rep_c3;
     float sw_c3, sw_c4, sw_c5;
+    int   ljpme;          /* 0 off, 1 LJ-PME geometric, 2 LJ-PME Lorentz-Berthelot */
+    float ewaldcoeff_lj, sh_lj_ewald;
 } ref_params_t;
 
 static void make_ic(const ref_params_t *p, interaction_const_t *ic)
 {
     memset(ic, 0, sizeof(*ic));
-    ic->vdwtype               = evdwCUT;
+    ic->vdwtype               = p->ljpme ? evdwPME : evdwCUT;
+    ic->ljpme_comb_rule       = p->ljpme == 2 ? ljcrLB : ljcrGEOM;
+    ic->ewaldcoeff_lj         = p->ewaldcoeff_lj;
+    ic->sh_lj_ewald           = p->sh_lj_ewald;
     ic->vdw_modifier          = p->vdw_modifier;
     ic->rvdw                  = p->rvdw;
     ic->rvdw_switch           = p->rvdw_switch;
@@ -356,6 +361,21 @@ ref_ctx_t *ref_kernel_ref_setup(int natoms, const float *xq, const int *type, in
     memset(&c->nbat, 0, sizeof(c->nbat));
     c->nbat.ntype = ntype; c->nbat.nbfp = malloc((size_t)ntype * ntype * 2 * sizeof(float));
     memcpy(c->nbat.nbfp, nbfp, (size_t)ntype * ntype * 2 * sizeof(float));
+    /* nbat->nbfp_comb as nbnxn_atomdata.c:397-429 fills it (that unit is unbuildable here, see header) */
+    c->nbat.comb_rule = p->ljpme == 1 ? ljcrGEOM : (p->ljpme == 2 ? ljcrLB : ljcrNONE);
+    c->nbat.nbfp_comb = calloc((size_t)ntype * 2, sizeof(float));
+    for (a = 0; a < ntype && p->ljpme; a++)
+    {
+        const double c6 = nbfp[(a * ntype + a) * 2], c12 = nbfp[(a * ntype + a) * 2 + 1];
+        if (p->ljpme == 1)
+        {
+            c->nbat.nbfp_comb[a * 2] = sqrt(c6); c->nbat.nbfp_comb[a * 2 + 1] = sqrt(c12);
+        }
+        else if (c6 > 0 && c12 > 0)
+        {
+            c->nbat.nbfp_comb[a * 2] = 0.5 * pow(c12 / c6, 1.0 / 6.0); c->nbat.nbfp_comb[a * 2 + 1] = sqrt(c6 * c6 / c12);
+        }
+    }
     c->nbat.natoms = natoms; c->nbat.natoms_local = natoms;
     c->nbat.type = c->type;
     c->nbat.XFormat = nbatXYZ; c->nbat.FFormat = nbatXYZ;
@@ -426,7 +446,7 @@ void ref_kernel_ref_free(ref_ctx_t *c)
     {
         free(c->nbat.out[l].f); free(c->nbat.out[l].fshift); free(c->nbat.out[l].Vvdw); free(c->nbat.out[l].Vc);
     }
-    free(c->nbat.out); free(c->nbat.nbfp);
+    free(c->nbat.out); free(c->nbat.nbfp); free(c->nbat.nbfp_comb);
     free(c->sl.ci); free(c->sl.cj);
     free(c->nbl); free(c->nblp);
     free(c->x3); free(c->q); free(c->type); free(c->shift_vec);

@@ -41,12 +41,13 @@ def small_case(name, system, ip, mcb=0):
           f"ref Vvdw {r_ref['Vvdw']:.6e} Vc {r_ref['Vc']:.6e}  gpu_ref Vvdw {r_gpu['Vvdw']:.6e} Vc {r_gpu['Vc']:.6e}")
 
 
-XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c3", "sw_c3", "sw_c4", "sw_c5"]
+XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c3", "sw_c3", "sw_c4", "sw_c5",
+           "vdwtype", "ljpme_comb_rule", "ewaldcoeff_lj", "sh_lj_ewald"]
 
 
 def switch_case(name, system, ip, mcb=0):
-    """LJ force / potential switch: only nbnxn_kernel_ref has these flavours (nbnxn_kernel_gpu_ref
-    is plain cut-off LJ), so the fixture holds its outputs alone."""
+    """LJ force / potential switch and LJ-PME: only nbnxn_kernel_ref has these flavours
+    (nbnxn_kernel_gpu_ref is plain cut-off LJ), so the fixture holds its outputs alone."""
     p = g.workload.prepare(system, ip, mcb)
     r_ref = O.RefKernelRef(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip).run(calc_ener=True)
     np.savez_compressed(
@@ -91,5 +92,13 @@ if __name__ == "__main__":
                 g.system.with_potential_switch(g.system.ewald(0.9), 0.7))
     switch_case("ljchain1000_ewald09_fswitch07", g.system.lj_chain_mixture(1000, ntype=8, seed=2026),
                 g.system.with_force_switch(g.system.ewald(0.9), 0.7), mcb=100)
+    switch_case("ljchain1000_ewald09_ljpme_geom", g.system.lj_chain_mixture(1000, ntype=8, seed=2026),
+                g.system.with_ljpme(g.system.ewald(0.9), g.abi.LJCR_GEOM))
+    switch_case("ljchain1000_ewald09_ljpme_lb", g.system.lj_chain_mixture(1000, ntype=8, seed=2026),
+                g.system.with_ljpme(g.system.ewald(0.9), g.abi.LJCR_LB), mcb=100)
+    switch_case("spc648_rf09_ljpme_geom", g.system.water_box(1, 1, 1),
+                g.system.with_ljpme(g.system.reaction_field(0.9), g.abi.LJCR_GEOM))
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        sys.exit(0)
     large_case("spc97k_rf10", (5, 5, 6), "spc", g.system.reaction_field(1.0))
     large_case("spce97k_ewald10", (5, 5, 6), "spce", g.system.ewald(1.0))

@@ -449,3 +449,118 @@ def test_lj_switch_fixtures_from_the_reference_kernel(nb, name):
     assert relrms(f, d["ref_f"]) < FORCE_RTOL
     assert abs(elj - float(d["ref_Vvdw"])) < 2e-5 * abs(float(d["ref_Vvdw"]))
     assert abs(eel - float(d["ref_Vc"])) < 1e-3 * abs(float(d["ref_Vc"]))    # one-float accumulation in the reference
+
+
+@pytest.mark.parametrize("el", ["rf", "ewald"])
+@pytest.mark.parametrize("rule", ["geometric", "lorentz-berthelot"])
+def test_ljpme_flavours(nb, el, rule):
+    """vdwtype = PME (LJ_EWALD_COMB_GEOM / _LB, nbnxn_cuda_kernel_utils.cuh:186-302) against
+    the oracle, whose LJ-PME arithmetic is pinned to the reference's nbnxn_kernel_ref in
+    tests/test_oracle_golden.py.  Water and the 8-type chain mixture (where the two rules differ);
+    F+V with pruning, F-only, F+V on the pruned list; the plain cut-off afterwards on the same handle."""
+    base = g.system.reaction_field(0.9) if el == "rf" else g.system.ewald(0.9)
+    ip = g.system.with_ljpme(base, abi.LJCR_GEOM if rule == "geometric" else abi.LJCR_LB)
+    for s in (g.system.water_box(5, 1, 1, model="spce"), g.system.lj_chain_mixture(3000)):
+        p = g.workload.prepare(s, ip, 200)
+        o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+        o_cut = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, base)
+        assert abs(o_cut["Vvdw"] - o["Vvdw"]) > 10 * ENERGY_RTOL * abs(o["Vvdw"])
+        _upload(nb, p, ip)
+        f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+        _check_against(f, e, p, ip, o)
+        f2, _ = nb.compute(p.xq, 0)
+        assert relrms(f2, o["f"]) < FORCE_RTOL
+        f3, e3 = nb.compute(p.xq, abi.FORCE_VIRIAL)
+        _check_against(f3, e3, p, ip, o)
+        _upload(nb, p, base)
+        f4, e4 = nb.compute(p.xq, abi.FORCE_VIRIAL)
+        _check_against(f4, e4, p, base, o_cut)
+
+
+@pytest.mark.parametrize("name", __import__("util").LJPME)
+def test_ljpme_fixtures_from_the_reference_kernel(nb, name):
+    """the HIP kernels straight against the reference's nbnxn_kernel_ref outputs for LJ-PME"""
+    p, ip, d = load_small(name)
+    _upload(nb, p, ip)
+    f, (elj, eel, fsh) = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert relrms(f, d["ref_f"]) < FORCE_RTOL
+    assert abs(elj - float(d["ref_Vvdw"])) < 2e-5 * abs(float(d["ref_Vvdw"]))
+    assert abs(eel - float(d["ref_Vc"])) < 1e-3 * abs(float(d["ref_Vc"]))    # one-float accumulation in the reference
+
+
+def test_ljpme_twin_range_many_types_and_struct_entry(nb):
+    """LJ-PME where the other template axes bite: rvdw < rcoulomb (the grid term has to obey the LJ
+    cut-off as well), 21 atom types (LJ and grid tables read from L2 instead of LDS), and the
+    struct-taking init_const reading vdwtype / ljpme_comb_rule / nbat->nbfp_comb."""
+    import dataclasses
+    import math
+    s = g.system.lj_chain_mixture(2500, ntype=20, seed=5)
+    base = g.system.with_ljpme(g.system.ewald(0.9, rlist=1.15), abi.LJCR_LB)
+    beta = g.system.calc_ewaldcoeff_q(1.1, 1e-5)
+    ip = dataclasses.replace(base, rcoulomb=1.1, ewaldcoeff_q=beta, sh_ewald=math.erfc(beta * 1.1))
+    p = g.workload.prepare(s, ip, 100)
+    assert p.ntype > 16
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    _upload(nb, p, ip)
+    _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ip, o)
+    f2, _ = nb.compute(p.xq, 0)
+    assert relrms(f2, o["f"]) < FORCE_RTOL
+    # the struct entry: cut-off LJ first so that a stale grid table cannot pass for the right one
+    _upload(nb, p, g.system.ewald(0.9, rlist=1.15))
+    nbfp = np.ascontiguousarray(p.nbfp, dtype=np.float32)
+    comb = g.system.nbfp_comb(nbfp, p.ntype, abi.LJCR_LB)
+    nbat = abi.Atomdata()
+    nbat.ntype, nbat.nbfp = p.ntype, abi.ptr(nbfp)
+    nbat.comb_rule, nbat.nbfp_comb = abi.LJCR_LB, abi.ptr(comb)
+    grp = abi.VerletGroup()
+    grp.nbat = C.pointer(nbat)
+    nb.init_const_struct(ip.to_struct(), grp)
+    _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ip, o)
+    # a combination rule the atom data does not carry is refused
+    nbat.comb_rule = abi.LJCR_GEOM
+    with pytest.raises(RuntimeError):
+        nb.init_const_struct(ip.to_struct(), grp)
+
+
+def test_tabulated_ewald_flavour(nb):
+    """eelCuEWALD_TAB(_TWIN) (nbnxn_cuda_kernel.cuh:451-458): the module's own force table against the
+    oracle's restatement of the reference's table filler, the kernels against the oracle evaluating
+    the same interpolation, against the analytical flavour, and the table following rcoulomb / beta
+    through nbnxn_cuda_pme_loadbal_update_param."""
+    import dataclasses
+    import math
+    s = g.system.water_box(2, 2, 2, model="spce")
+    ana = g.system.ewald(0.9, rlist=1.1)
+    ip = g.system.with_tabulated_ewald(ana)
+    p = g.workload.prepare(s, ip, 300)
+    _upload(nb, p, ip)
+    assert not nb.is_kernel_ewald_analytical()
+    tab, scale = nb.coulomb_tab()
+    tab_o, scale_o = O.ewald_force_table(ip.ewaldcoeff_q, ip.rcoulomb)
+    assert len(tab) == len(tab_o) == 1536 and scale == pytest.approx(scale_o, rel=1e-7)
+    # same table up to the half-ulp of the round trip through the kernel's units
+    assert np.abs(tab - tab_o).max() <= 2.4e-7 * np.abs(tab_o).max()
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    o_ana = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ana)
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    _check_against(f, e, p, ip, o)
+    assert relrms(f, o_ana["f"]) < FORCE_RTOL
+    f2, _ = nb.compute(p.xq, 0)
+    assert relrms(f2, o["f"]) < FORCE_RTOL
+    # PME load balancing: rcoulomb 1.0, new beta -> new table, twin-range kernels
+    beta = g.system.calc_ewaldcoeff_q(1.0, 1e-5)
+    ip2 = dataclasses.replace(ip, rcoulomb=1.0, ewaldcoeff_q=beta, sh_ewald=math.erfc(beta * 1.0))
+    nb.pme_loadbal_update_param(ip2.to_struct())
+    tab2, scale2 = nb.coulomb_tab()
+    assert scale2 == pytest.approx(1534 / 1.0, rel=1e-6) and np.abs(tab2 - tab).max() > 1e-3
+    o2 = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip2)
+    _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ip2, o2)
+    # tabulated electrostatics under LJ-PME and under the force switch
+    for ipx in (g.system.with_ljpme(ip, abi.LJCR_GEOM), g.system.with_force_switch(ip, 0.7)):
+        _upload(nb, p, ipx)
+        ox = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ipx)
+        _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ipx, ox)
+    # back to the analytical flavour on the same handle
+    _upload(nb, p, ana)
+    assert nb.is_kernel_ewald_analytical()
+    _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ana, o_ana)

@@ -26,8 +26,10 @@ def relrms(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 
 
-XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c3", "sw_c3", "sw_c4", "sw_c5"]
+XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c3", "sw_c3", "sw_c4", "sw_c5",
+           "vdwtype", "ljpme_comb_rule", "ewaldcoeff_lj", "sh_lj_ewald"]     # older fixtures stop at sw_c5
 SWITCH = ["spc648_rf09_fswitch07", "ljchain1000_ewald09_pswitch07", "ljchain1000_ewald09_fswitch07"]
+LJPME = ["ljchain1000_ewald09_ljpme_geom", "ljchain1000_ewald09_ljpme_lb", "spc648_rf09_ljpme_geom"]
 
 
 def params_from_array(arr, ext=None):
@@ -35,7 +37,9 @@ def params_from_array(arr, ext=None):
     kw["el_type"] = int(kw["el_type"])
     if ext is not None:
         kw.update({k: float(v) for k, v in zip(XFIELDS, ext)})
-        kw["vdw_modifier"] = int(kw["vdw_modifier"])
+        for k in ("vdw_modifier", "vdwtype", "ljpme_comb_rule"):
+            if k in kw:
+                kw[k] = int(kw[k])
     return InteractionParams(**kw)
 
 
