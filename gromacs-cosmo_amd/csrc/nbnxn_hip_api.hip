@@ -14,6 +14,7 @@
 
 #include "nbnxn_hip.h"
 #include "nbnxn_kernel.h"
+#include "nbnxn_search.h"
 
 namespace {
 
@@ -140,6 +141,11 @@ struct nbnxn_hip {
     float        *h_fa = nullptr;   // pinned landing area of d_fa
     size_t        h_fa_alloc = 0;
     int           natoms_real = 0;
+    // device-side pair search (nbnxn_hip_put_on_grid / nbnxn_hip_make_pairlist), created on first use
+    nbx_search   *search = nullptr;
+    bool          grid_on_device = false;   // the atom arrays in use came from nbnxn_hip_put_on_grid
+    DevBuf<int>   d_type_in, d_excl_index, d_excl_a;   // caller-order types; topology exclusions (CSR)
+    DevBuf<float> d_q_in;
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
 
     nbx_wallclock_gpu_t timings;
@@ -388,6 +394,7 @@ int init_atomdata_impl(nbnxn_hip *nb, int natoms, int natoms_local, int ntype, c
     nb->natoms = natoms; nb->natoms_local = natoms_local;
     nb->clean_other = false;   // the idle half was zeroed for the old atom count
     nb->d_a.n = 0; nb->d_cell.n = 0;   // a new grid: the atom order has to be set again
+    nb->grid_on_device = false;
     hipStream_t st = nb->stream[0];
     if (re && natoms > 0)
     {
@@ -882,6 +889,9 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     (void)hipFree(nb->shift_vec);
     (void)hipHostFree(nb->h_stage);
     dev_free(nb->d_a); dev_free(nb->d_cell); dev_free(nb->d_x); dev_free(nb->d_fa);
+    dev_free(nb->c6grid); dev_free(nb->coulomb_tab);
+    dev_free(nb->d_type_in); dev_free(nb->d_excl_index); dev_free(nb->d_excl_a); dev_free(nb->d_q_in);
+    nbx_search_destroy(nb->search); nb->search = nullptr;
     if (nb->h_fa) { (void)hipHostFree(nb->h_fa); }
     if (nb->two_streams)
     {
@@ -1119,6 +1129,147 @@ int nbnxn_hip_set_atom_order(nbnxn_hip_ptr_t nb, int natoms_real, const int *a, 
     if (natoms_real > 0) { HIP_TRY(hipMemcpyAsync(nb->d_cell.p, cell, (size_t)natoms_real * sizeof(int), hipMemcpyHostToDevice, st)); }
     HIP_TRY(hipStreamSynchronize(st));
     nb->natoms_real = natoms_real;
+    return 0;
+}
+
+// ---- pair search on the device ----
+
+int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
+                          int x_on_device, const int *type, const float *q, float atom_density)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->have_const) { return nbx_fail("put_on_grid before init_const (the number of atom types comes from there)"); }
+    if (natoms <= 0 || !box || !x || !type || !q) { return nbx_fail("put_on_grid: missing atoms, box, types or charges"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    for (int i = 0; i < natoms; i++)
+    {
+        if (type[i] < 0 || type[i] >= nb->ntype - 1) { return nbx_fail("atom %d has type %d outside [0,%d)", i, type[i], nb->ntype - 1); }
+    }
+    if (!nb->search) { nb->search = nbx_search_create(); }
+    nb->grid_on_device = false;
+    hipStream_t st = nb->stream[0];
+    const float *d_x = x;
+    if (dev_reserve(nb->d_type_in, natoms) || dev_reserve(nb->d_q_in, natoms)) { return 1; }
+    if (!x_on_device)
+    {
+        if (dev_reserve(nb->d_x, (size_t)natoms * 3)) { return 1; }
+        HIP_TRY(hipMemcpyAsync(nb->d_x.p, x, (size_t)natoms * 3 * sizeof(float), hipMemcpyHostToDevice, st));
+        d_x = nb->d_x.p;
+    }
+    HIP_TRY(hipMemcpyAsync(nb->d_type_in.p, type, (size_t)natoms * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(nb->d_q_in.p, q, (size_t)natoms * sizeof(float), hipMemcpyHostToDevice, st));
+    const int all_pbc[3] = {1, 1, 1};
+    if (nbx_search_grid_columns(nb->search, st, box, pbc_shift_dim ? pbc_shift_dim : all_pbc, natoms, d_x, atom_density))
+    {
+        return nbx_fail("put_on_grid: %s", nbx_search_error());
+    }
+    const int npad = nbx_search_natoms_padded(nb->search);
+    // what nbnxn_cuda_init_atomdata does for a new grid (nbnxn_cuda_data_mgmt.cu:853-912)
+    bool re = false;
+    if (dev_reserve(nb->xq, npad) || dev_reserve(nb->type, npad) || reserve_f(nb, (size_t)npad * 3, &re)) { return 1; }
+    nb->natoms = npad; nb->natoms_local = npad;
+    nb->clean_other = false;
+    if (re) { HIP_TRY(hipMemsetAsync(nb->f.p, 0, nb->f.alloc * sizeof(float), st)); }
+    nb->plist[0].nsci = 0; nb->plist[1].nsci = 0;
+    if (nbx_search_grid_fill(nb->search, st, d_x, nb->d_q_in.p, nb->d_type_in.p, nb->ntype, nb->xq.p, nb->type.p))
+    {
+        return nbx_fail("put_on_grid: %s", nbx_search_error());
+    }
+    // the atom order for copy_x_to_xq / add_f, without a trip through the host
+    if (dev_reserve(nb->d_a, npad) || dev_reserve(nb->d_cell, natoms) || dev_reserve(nb->d_x, (size_t)natoms * 3)
+        || dev_reserve(nb->d_fa, (size_t)natoms * 3)) { return 1; }
+    if ((size_t)natoms * 3 > nb->h_fa_alloc)
+    {
+        if (nb->h_fa) { HIP_TRY(hipHostFree(nb->h_fa)); nb->h_fa = nullptr; }
+        nb->h_fa_alloc = (size_t)natoms * 3 + (size_t)natoms * 3 / 5 + 64;
+        HIP_TRY(hipHostMalloc((void **)&nb->h_fa, nb->h_fa_alloc * sizeof(float), hipHostMallocDefault));
+    }
+    HIP_TRY(hipMemcpyAsync(nb->d_a.p, nbx_search_atom_order(nb->search), (size_t)npad * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(nb->d_cell.p, nbx_search_cell_index(nb->search), (size_t)natoms * sizeof(int), hipMemcpyDeviceToDevice, st));
+    nb->natoms_real = natoms;
+    // shift vectors of the rectangular box, XYZ2IS order (types/ishift.h:45-55)
+    float sv[NBX_SHIFTS * 3];
+    int   is = 0;
+    for (int tz = -1; tz <= 1; tz++)
+    {
+        for (int ty = -1; ty <= 1; ty++)
+        {
+            for (int tx = -2; tx <= 2; tx++, is++)
+            {
+                sv[3 * is] = tx * box[0]; sv[3 * is + 1] = ty * box[1]; sv[3 * is + 2] = tz * box[2];
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(nb->shift_vec, sv, sizeof(sv), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    nb->shift_vec_uploaded = true;
+    nb->grid_on_device     = true;
+    return 0;
+}
+
+int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced)
+{
+    if (check_handle(nb)) { return 1; }
+    if (iloc != NBX_LOCAL) { return nbx_fail("the device pair search builds the local list of the home zone only (iloc %d)", iloc); }
+    if (!nb->search || !nb->grid_on_device || nbx_search_natoms_padded(nb->search) != nb->natoms) { return nbx_fail("make_pairlist before put_on_grid (or after a new init_atomdata)"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = nb->stream[0];
+    const int  *d_ei = nullptr, *d_ea = nullptr;
+    if (excl_index && excl_a)
+    {
+        const int n = nb->natoms_real, ne = excl_index[n];
+        if (excl_index[0] != 0 || ne < 0) { return nbx_fail("exclusion index does not start at 0 / ends at %d", ne); }
+        if (dev_reserve(nb->d_excl_index, (size_t)n + 1) || dev_reserve(nb->d_excl_a, (size_t)ne + 1)) { return 1; }
+        HIP_TRY(hipMemcpyAsync(nb->d_excl_index.p, excl_index, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        if (ne > 0) { HIP_TRY(hipMemcpyAsync(nb->d_excl_a.p, excl_a, (size_t)ne * sizeof(int), hipMemcpyHostToDevice, st)); }
+        d_ei = nb->d_excl_index.p; d_ea = nb->d_excl_a.p;
+    }
+    nbx_search_list_t L;
+    if (nbx_search_make_pairlist(nb->search, st, rlist, min_ci_balanced, d_ei, d_ea, nb->xq.p, &L))
+    {
+        return nbx_fail("make_pairlist: %s", nbx_search_error());
+    }
+    // what nbnxn_cuda_init_pairlist does (nbnxn_cuda_data_mgmt.cu:759-800), device to device
+    PList &pl = nb->plist[iloc];
+    if (dev_reserve(pl.sci, L.nsci) || dev_reserve(pl.cj4, L.ncj4) || dev_reserve(pl.excl, L.nexcl)) { return 1; }
+    if (L.nsci > 0)
+    {
+        HIP_TRY(hipMemcpyAsync(pl.sci.p, L.sci, (size_t)L.nsci * sizeof(nbx_sci_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl.cj4.p, L.cj4, (size_t)L.ncj4 * sizeof(nbx_cj4_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl.excl.p, L.excl, (size_t)L.nexcl * sizeof(nbx_excl_t), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    pl.nsci = L.nsci; pl.ncj4 = L.ncj4; pl.nexcl = L.nexcl; pl.nci_tot = L.nci_tot; pl.rlist = rlist;
+    pl.do_prune = true;
+    return 0;
+}
+
+int nbnxn_hip_download_grid(nbnxn_hip_ptr_t nb, int *dims, int *a, int *cell, float *bb, float *bbcz, int *nsubc, float *xq, int *type)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->search || !nb->grid_on_device || nbx_search_natoms_padded(nb->search) != nb->natoms) { return nbx_fail("download_grid before put_on_grid"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    if (dims)
+    {
+        if (nbx_search_grid_info(nb->search, &dims[0], &dims[1], &dims[2])) { return nbx_fail("download_grid: %s", nbx_search_error()); }
+        dims[3] = nb->natoms;
+    }
+    if (nbx_search_download_grid(nb->search, nb->stream[0], a, cell, bb, bbcz, nsubc)) { return nbx_fail("download_grid: %s", nbx_search_error()); }
+    if (xq) { HIP_TRY(hipMemcpy(xq, nb->xq.p, (size_t)nb->natoms * sizeof(float4), hipMemcpyDeviceToHost)); }
+    if (type) { HIP_TRY(hipMemcpy(type, nb->type.p, (size_t)nb->natoms * sizeof(int), hipMemcpyDeviceToHost)); }
+    return 0;
+}
+
+int nbnxn_hip_download_pairlist(nbnxn_hip_ptr_t nb, int iloc, int *counts, nbx_sci_t *sci, nbx_cj4_t *cj4, nbx_excl_t *excl)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    const PList &pl = nb->plist[iloc];
+    if (counts) { counts[0] = pl.nsci; counts[1] = pl.ncj4; counts[2] = pl.nexcl; counts[3] = pl.nci_tot; }
+    HIP_TRY(hipStreamSynchronize(nb->stream[iloc]));
+    if (sci && pl.nsci > 0) { HIP_TRY(hipMemcpy(sci, pl.sci.p, (size_t)pl.nsci * sizeof(nbx_sci_t), hipMemcpyDeviceToHost)); }
+    if (cj4 && pl.ncj4 > 0) { HIP_TRY(hipMemcpy(cj4, pl.cj4.p, (size_t)pl.ncj4 * sizeof(nbx_cj4_t), hipMemcpyDeviceToHost)); }
+    if (excl && pl.nexcl > 0) { HIP_TRY(hipMemcpy(excl, pl.excl.p, (size_t)pl.nexcl * sizeof(nbx_excl_t), hipMemcpyDeviceToHost)); }
     return 0;
 }
 

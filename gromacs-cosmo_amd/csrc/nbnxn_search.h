@@ -1,0 +1,58 @@
+// Internal interface of the device-side pair search (nbnxn_search.hip, nbnxn_search_prims.hip).
+// Not part of the public ABI; the C entry points are in nbnxn_hip_api.hip.
+#ifndef NBNXN_SEARCH_H
+#define NBNXN_SEARCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "nbnxn_hip.h"
+
+struct nbx_search;
+
+nbx_search *nbx_search_create();
+void        nbx_search_destroy(nbx_search *s);
+// text of the last failure of a call that returned non-zero
+const char *nbx_search_error();
+
+// Stage 1 of nbnxn_put_on_grid (nbnxn_search.c:1777): column grid over [0, box) from the atom
+// density, atoms bucketed per column and ordered by z.  d_x is [n][3] in caller order, on the
+// device.  Synchronises the stream once (the padded atom count sizes the caller's arrays).
+int nbx_search_grid_columns(nbx_search *s, hipStream_t st, const float box[3], const int pbc_shift_dim[3], int n,
+                            const float *d_x, float atom_density);
+int nbx_search_natoms_padded(const nbx_search *s);
+// Stage 2: per super-cell ordering in y and x, bounding boxes, and the grid-ordered atom data
+// (coordinates + charge with fillers, types with the dummy type): nbnxn_atomdata_set /
+// nbnxn_atomdata_copy_x_to_nbat_x of the reference folded into the gridding pass.
+int nbx_search_grid_fill(nbx_search *s, hipStream_t st, const float *d_x, const float *d_q, const int *d_type,
+                         int ntype_with_dummy, float4 *d_xq, int *d_type_out);
+// device arrays: grid slot -> caller atom (-1 filler) [natoms_padded]; caller atom -> grid slot [n]
+const int *nbx_search_atom_order(const nbx_search *s);
+const int *nbx_search_cell_index(const nbx_search *s);
+
+struct nbx_search_list_t {
+    int               nsci, ncj4, nexcl, nci_tot;
+    const nbx_sci_t  *sci;
+    const nbx_cj4_t  *cj4;
+    const nbx_excl_t *excl;
+};
+
+// nbnxn_make_pairlist (nbnxn_search.c:5583) for the home zone: the local list in the GPU format,
+// left on the device.  d_excl_index [n+1] / d_excl_a: topology exclusions (t_blocka), may be null.
+int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min_ci_balanced, const int *d_excl_index,
+                             const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out);
+
+// verification: grid geometry and per-cluster data back on the host
+int nbx_search_grid_info(const nbx_search *s, int *ncx, int *ncy, int *nc);
+int nbx_search_download_grid(const nbx_search *s, hipStream_t st, int *a, int *cell, float *bb, float *bbcz, int *nsubc);
+
+// --- nbnxn_search_prims.hip: library scans / sorts behind plain signatures (hipCUB is heavy to
+// compile and must not see -ffp-contract=off) ---
+struct nbx_prim_tmp { void *p = nullptr; size_t bytes = 0; };
+hipError_t nbx_prim_exclusive_sum(nbx_prim_tmp &tmp, const int *in, int *out, int n, hipStream_t st);
+hipError_t nbx_prim_sort_u64_int(nbx_prim_tmp &tmp, const unsigned long long *k_in, unsigned long long *k_out, const int *v_in,
+                                 int *v_out, int n, int end_bit, hipStream_t st);
+hipError_t nbx_prim_sort_u32_sci(nbx_prim_tmp &tmp, const unsigned *k_in, unsigned *k_out, const nbx_sci_t *v_in, nbx_sci_t *v_out,
+                                 int n, int end_bit, hipStream_t st);
+void       nbx_prim_free(nbx_prim_tmp &tmp);
+
+#endif

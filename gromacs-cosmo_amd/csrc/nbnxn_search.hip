@@ -1,0 +1,843 @@
+// Pair search on the device: gridding and construction of the cluster-pair list
+// in the GPU format (nbnxn_sci_t / nbnxn_cj4_t / nbnxn_excl_t), home zone, without the atoms or
+// the list ever visiting the host.
+//
+// WHAT is built follows GROMACS 5.0.4: nbnxn_put_on_grid (nbnxn_search.c:1777: set_grid_size_xy
+// :433-486, calc_column_indices :1493-1590, sort_columns_supersub :1374-1490, fill_cell :1164),
+// nbnxn_make_pairlist (:5583: make_cluster_list_supersub :2955-3123, set_self_and_newton_excls
+// :2759-2780, set_sci_top_excls :3673-3807, split_sci_entry :3936-4024, sort_sci :5517-5580).
+// HOW is specific to the device: no per-thread lists that get combined, but count -> scan ->
+// fill passes over a fixed enumeration of (i super-cell, shift) entries, one wave64 per entry,
+// the 64 lanes testing 64 candidate j-clusters at a time and compacting the survivors with a
+// ballot; every float decision (column index, bounding-box distance, atom distance) is made
+// with the same IEEE operations in the same order as the host-side builder
+// (nbnxn_host.cpp), and this file is compiled with -ffp-contract=off, so that both produce the
+// SAME list -- which is how tests/test_gpu_search.py checks it, entry for entry.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "nbnxn_search.h"
+
+namespace {
+
+constexpr int   NA_C     = NBX_CLUSTER_SIZE;
+constexpr int   NSUBC    = NBX_NCL_PER_SUPERCL;
+constexpr int   NA_SC    = NA_C * NSUBC;
+constexpr float FAR_AWAY = 107.0f;   // nbnxn_atomdata.c:256
+constexpr int   NSHIFT_HALF = 14;    // shifts <= CENTRAL with |t| <= 1 in every dimension
+
+thread_local std::string g_err;
+
+int sfail(const char *fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define S_TRY(call)                                                                                  \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) { return sfail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } \
+    } while (0)
+
+template <typename T>
+struct Buf {
+    T     *p = nullptr;
+    size_t alloc = 0;
+    int reserve(size_t n)
+    {
+        if (n <= alloc && p) { return 0; }
+        if (p) { (void)hipFree(p); p = nullptr; alloc = 0; }
+        const size_t na = n + n / 4 + 64;
+        if (hipMalloc((void **)&p, na * sizeof(T)) != hipSuccess) { return sfail("hipMalloc of %zu bytes failed", na * sizeof(T)); }
+        alloc = na;
+        return 0;
+    }
+    void release() { if (p) { (void)hipFree(p); } p = nullptr; alloc = 0; }
+};
+
+struct GridDims {
+    float c0[3];
+    int   ncx, ncy;
+    float sx, sy, inv_sx, inv_sy;
+};
+
+struct ListParams {
+    GridDims g;
+    int      nc;
+    float    box[3];
+    int      shp[3];
+    float    rlist, rl2, rbb2;
+};
+
+// the 14 shifts of a half list in ascending shift index (XYZ2IS, types/ishift.h:45-55), which is
+// the order the reference's tz / ty / tx loops visit them (nbnxn_search.c:5060-5096)
+__device__ __constant__ signed char c_shift_t[NSHIFT_HALF][3] = {
+    {-1, -1, -1}, {0, -1, -1}, {1, -1, -1}, {-1, 0, -1}, {0, 0, -1}, {1, 0, -1}, {-1, 1, -1}, {0, 1, -1}, {1, 1, -1},
+    {-1, -1, 0},  {0, -1, 0},  {1, -1, 0},  {-1, 0, 0},  {0, 0, 0}};
+
+__device__ __forceinline__ int shift_index(int tx, int ty, int tz) { return 5 * (3 * (tz + 1) + ty + 1) + tx + 2; }
+
+// ------------------------------------------------------------------------------------------
+// gridding
+// ------------------------------------------------------------------------------------------
+
+// calc_column_indices: column of every atom (clamped: rounding at the upper edge), column
+// populations, and the sort key (column, z) whose stable sort reproduces "z ascending, ties by
+// atom index" of the host builder
+__global__ void k_columns(int n, const float *__restrict__ x, GridDims g, int *__restrict__ cxy_na,
+                          unsigned long long *__restrict__ key, int *__restrict__ val)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) { return; }
+    const float px = x[3 * i], py = x[3 * i + 1];
+    const float pz = x[3 * i + 2] + 0.0f;   // -0 -> +0: they compare equal and must sort as equal
+    int         cx = (int)floorf((px - g.c0[0]) * g.inv_sx);
+    int         cy = (int)floorf((py - g.c0[1]) * g.inv_sy);
+    cx = min(max(cx, 0), g.ncx - 1);
+    cy = min(max(cy, 0), g.ncy - 1);
+    const int col = cx * g.ncy + cy;
+    atomicAdd(&cxy_na[col], 1);
+    unsigned u = __float_as_uint(pz);
+    u          = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    key[i]     = ((unsigned long long)(unsigned)col << 32) | u;
+    val[i]     = i;
+}
+
+// super-cells per column; entry ncxy is the zero that makes the exclusive scans yield the totals
+__global__ void k_column_cells(int ncxy, int *__restrict__ cxy_na, int *__restrict__ ncz)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncxy) { return; }
+    if (c == ncxy) { cxy_na[c] = 0; ncz[c] = 0; return; }
+    ncz[c] = (cxy_na[c] + NA_SC - 1) / NA_SC;
+}
+
+struct SortItem {
+    float key;
+    int   idx;
+};
+
+__device__ __forceinline__ bool item_less(const SortItem &a, const SortItem &b)
+{
+    return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+}
+
+// ascending bitonic sort of one item per lane within aligned groups of N lanes
+template <int N>
+__device__ __forceinline__ void group_sort(SortItem &v, int lane)
+{
+    const int l = lane & (N - 1);
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+    {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+            SortItem o;
+            o.key = __shfl_xor(v.key, j);
+            o.idx = __shfl_xor(v.idx, j);
+            const bool up       = (l & k) == 0;
+            const bool lower    = (l & j) == 0;
+            const bool want_min = (up == lower);
+            const bool o_less   = item_less(o, v);
+            if (want_min == o_less) { v = o; }
+        }
+    }
+}
+
+// sort_columns_supersub + fill_cell for one super-cell per wave: the column's atoms arrive
+// z-ordered; each half of 32 is ordered in y, each quarter of 16 in x; then bounding boxes per
+// cluster, the atom-order arrays and the grid-ordered atom data with fillers
+// (nbnxn_atomdata.c:288-295, 873, 937-951).
+__global__ void __launch_bounds__(64)
+k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, const int *__restrict__ cxy_na,
+             const int *__restrict__ atom_start, const int *__restrict__ sorted_atom, const float *__restrict__ x,
+             const float *__restrict__ q, const int *__restrict__ type, int dummy_type, int *__restrict__ a_out,
+             int *__restrict__ cell_out, float4 *__restrict__ xq, int *__restrict__ type_out, float *__restrict__ bb,
+             float *__restrict__ bbcz, int *__restrict__ nsubc, int *__restrict__ nsubc_tot)
+{
+    const int sc   = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (sc >= nc) { return; }
+    // the column that holds this super-cell: the last c with cxy_ind[c] <= sc (empty columns repeat an index)
+    int lo = 0, hi = ncxy;
+    while (hi - lo > 1)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (cxy_ind[mid] <= sc) { lo = mid; } else { hi = mid; }
+    }
+    const int c    = lo;
+    const int k    = sc - cxy_ind[c];
+    const int na   = cxy_na[c];
+    const int na_c = min(NA_SC, na - k * NA_SC);
+    const int off  = k * NA_SC + lane;
+    int       at   = off < na ? sorted_atom[atom_start[c] + off] : -1;
+
+    // z-range of the super-cell from the z-ordered atoms
+    const float pz_sorted = at >= 0 ? x[3 * at + 2] : 0.0f;
+    const float z_first   = __shfl(pz_sorted, 0);
+    const float z_last    = __shfl(pz_sorted, na_c - 1);
+
+    SortItem v;
+    v.idx = at >= 0 ? at : INT_MAX;
+    v.key = at >= 0 ? x[3 * at + 1] : INFINITY;
+    group_sort<32>(v, lane);
+    v.key = v.idx != INT_MAX ? x[3 * v.idx + 0] : INFINITY;
+    group_sort<16>(v, lane);
+    at = v.idx != INT_MAX ? v.idx : -1;
+
+    float px = 0, py = 0, pz = 0;
+    if (at >= 0) { px = x[3 * at]; py = x[3 * at + 1]; pz = x[3 * at + 2]; }
+    float blo[3] = {at >= 0 ? px : 1e30f, at >= 0 ? py : 1e30f, at >= 0 ? pz : 1e30f};
+    float bhi[3] = {at >= 0 ? px : -1e30f, at >= 0 ? py : -1e30f, at >= 0 ? pz : -1e30f};
+#pragma unroll
+    for (int m = 1; m < NA_C; m <<= 1)
+    {
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+        {
+            blo[d] = fminf(blo[d], __shfl_xor(blo[d], m));
+            bhi[d] = fmaxf(bhi[d], __shfl_xor(bhi[d], m));
+        }
+    }
+    const int  cl_in_sc   = lane >> 3;
+    const bool cl_has_atoms = (cl_in_sc * NA_C) < na_c;
+    if ((lane & 7) == 0)
+    {
+        float *b = bb + ((size_t)sc * NSUBC + cl_in_sc) * 6;
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+        {
+            b[d]     = cl_has_atoms ? blo[d] : 0.0f;
+            b[3 + d] = cl_has_atoms ? bhi[d] : 0.0f;
+        }
+    }
+    if (lane == 0)
+    {
+        const int ns  = min(NSUBC, (na_c + NA_C - 1) / NA_C);
+        nsubc[sc]     = ns;
+        bbcz[2 * sc]     = z_first;
+        bbcz[2 * sc + 1] = z_last;
+        atomicAdd(nsubc_tot, ns);
+    }
+
+    const size_t gi = (size_t)sc * NA_SC + lane;
+    a_out[gi]       = at;
+    if (at >= 0)
+    {
+        cell_out[at] = (int)gi;
+        xq[gi]       = make_float4(px, py, pz, q[at]);
+        type_out[gi] = type[at];
+    }
+    else
+    {
+        // filler: its cluster's grid coordinates, distinct z per atom
+        const int cx = c / g.ncy, cy = c - cx * g.ncy;
+        const int gx = cx * 2 + ((lane >> 3) & 1), gy = cy * 2 + ((lane >> 4) & 1), gz = k * 2 + (lane >> 5);
+        xq[gi]       = make_float4(-FAR_AWAY * (1 + NA_C * gx), -FAR_AWAY * (1 + NA_C * gy), -FAR_AWAY * (1 + NA_C * gz + (lane & 7)), 0.0f);
+        type_out[gi] = dummy_type;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// list construction
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float sqr(float v) { return v * v; }
+
+// distance^2 between two bounding boxes (nbnxn_search.c:2113-2144), a: {lo[3], hi[3]}
+__device__ __forceinline__ float bb_dist2(const float *a, const float *b)
+{
+    float d2 = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+    {
+        const float dl = a[d] - b[3 + d];
+        const float dh = b[d] - a[3 + d];
+        const float dm = fmaxf(fmaxf(dl, dh), 0.0f);
+        d2 += dm * dm;
+    }
+    return d2;
+}
+
+// One wave per entry e = (i super-cell) * 14 + (shift slot).  FILL = false: ncj[e] = number of
+// j-clusters the entry keeps.  FILL = true: the cj4 groups of the entry are written at
+// cj4_start[e] (the array was zeroed), the groups holding the entry's own clusters are marked
+// as needing exclusion words, and the cluster pairs are counted into nci_tot.
+template <bool FILL>
+__global__ void __launch_bounds__(64)
+k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ nsubc, const float *__restrict__ bb,
+       const float *__restrict__ bbcz, const float4 *__restrict__ xq, int *__restrict__ ncj,
+       const int *__restrict__ cj4_start, nbx_cj4_t *__restrict__ cj4, int *__restrict__ need_excl,
+       unsigned *__restrict__ nci_tot)
+{
+    const int e    = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int sci  = e / NSHIFT_HALF;
+    const int ss   = e - sci * NSHIFT_HALF;
+    const int tx = c_shift_t[ss][0], ty = c_shift_t[ss][1], tz = c_shift_t[ss][2];
+    const int nsub_i = nsubc[sci];
+    const bool active = nsub_i > 0 && abs(tx) <= P.shp[0] && abs(ty) <= P.shp[1] && abs(tz) <= P.shp[2];
+    if (!active)
+    {
+        if (!FILL && lane == 0) { ncj[e] = 0; }
+        return;
+    }
+    const int   shift = shift_index(tx, ty, tz);
+    const float sh[3] = {tx * P.box[0], ty * P.box[1], tz * P.box[2]};
+    const bool  central = (shift == NBX_CENTRAL);
+
+    __shared__ float s_bbi[NSUBC][6];   // shifted i-cluster boxes
+    __shared__ float s_xi[NA_SC][3];    // shifted i-atoms
+    if (lane < NSUBC * 6)
+    {
+        const int ci = lane / 6, w = lane - ci * 6;
+        s_bbi[ci][w] = bb[((size_t)sci * NSUBC + ci) * 6 + w] + sh[w % 3];
+    }
+    {
+        const float4 xa = xq[(size_t)sci * NA_SC + lane];
+        s_xi[lane][0] = xa.x + sh[0];
+        s_xi[lane][1] = xa.y + sh[1];
+        s_xi[lane][2] = xa.z + sh[2];
+    }
+    __syncthreads();
+    // box of the whole i super-cell: unshifted union first, then shifted (the host's order of operations)
+    float bS[6];
+    {
+#pragma unroll
+        for (int w = 0; w < 6; w++) { bS[w] = w < 3 ? 1e30f : -1e30f; }
+        for (int ci = 0; ci < nsub_i; ci++)
+        {
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+            {
+                bS[d]     = fminf(bS[d], bb[((size_t)sci * NSUBC + ci) * 6 + d]);
+                bS[3 + d] = fmaxf(bS[3 + d], bb[((size_t)sci * NSUBC + ci) * 6 + 3 + d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) { bS[d] += sh[d]; bS[3 + d] += sh[d]; }
+    }
+    const GridDims &g = P.g;
+    int cxf = (int)floorf((bS[0] - P.rlist - g.c0[0]) * g.inv_sx);
+    int cxl = (int)floorf((bS[3] + P.rlist - g.c0[0]) * g.inv_sx);
+    int cyf = (int)floorf((bS[1] - P.rlist - g.c0[1]) * g.inv_sy);
+    int cyl = (int)floorf((bS[4] + P.rlist - g.c0[1]) * g.inv_sy);
+    cxf = max(cxf, 0); cxl = min(cxl, g.ncx - 1);
+    cyf = max(cyf, 0); cyl = min(cyl, g.ncy - 1);
+
+    int       running = 0;   // j-clusters kept so far (wave-uniform)
+    unsigned  npairs  = 0;   // cluster pairs of this lane's j-clusters
+    const int base4   = FILL ? cj4_start[e] : 0;
+
+    for (int cx = cxf; cx <= cxl; cx++)
+    {
+        float       d2x   = 0;
+        const float colx0 = g.c0[0] + cx * g.sx, colx1 = colx0 + g.sx;
+        if (colx0 > bS[3]) { d2x = sqr(colx0 - bS[3]); }
+        else if (colx1 < bS[0]) { d2x = sqr(bS[0] - colx1); }
+        if (d2x >= P.rl2) { continue; }
+        for (int cy = cyf; cy <= cyl; cy++)
+        {
+            float       d2xy  = d2x;
+            const float coly0 = g.c0[1] + cy * g.sy, coly1 = coly0 + g.sy;
+            if (coly0 > bS[4]) { d2xy += sqr(coly0 - bS[4]); }
+            else if (coly1 < bS[1]) { d2xy += sqr(bS[1] - coly1); }
+            if (d2xy >= P.rl2) { continue; }
+            int       c0 = cxy_ind[cx * g.ncy + cy];
+            const int c1 = cxy_ind[cx * g.ncy + cy + 1];
+            if (central) { c0 = max(c0, sci); }   // half list: j super-cells >= i (:5270-5283)
+            for (int cb = c0; cb < c1; cb += 8)
+            {
+                const int scj = cb + (lane >> 3);
+                const int cjo = lane & 7;
+                unsigned  mb  = 0;
+                if (scj < c1 && cjo < nsubc[scj])
+                {
+                    float       d2 = d2xy;
+                    const float z0 = bbcz[2 * scj], z1 = bbcz[2 * scj + 1];
+                    if (z0 > bS[5]) { d2 += sqr(z0 - bS[5]); }
+                    else if (z1 < bS[2]) { d2 += sqr(bS[2] - z1); }
+                    if (d2 < P.rl2)
+                    {
+                        const int cj = scj * NSUBC + cjo;
+                        float     bj[6];
+#pragma unroll
+                        for (int w = 0; w < 6; w++) { bj[w] = bb[(size_t)cj * 6 + w]; }
+                        const int ci1 = (central && sci == scj) ? cjo + 1 : nsub_i;
+                        int       np = 0, ci_last = -1;
+                        float     d2_last = 0;
+                        for (int ci = 0; ci < ci1; ci++)
+                        {
+                            const float d2c = bb_dist2(s_bbi[ci], bj);
+                            if (d2c < P.rl2) { mb |= 1u << ci; ci_last = ci; d2_last = d2c; np++; }
+                        }
+                        // a lone cluster pair beyond the box-only radius gets the atom check (:3073-3092)
+                        if (np == 1 && d2_last >= P.rbb2)
+                        {
+                            bool in_range = false;
+                            for (int i = 0; i < NA_C && !in_range; i++)
+                            {
+                                const float *xi = s_xi[ci_last * NA_C + i];
+                                for (int j = 0; j < NA_C; j++)
+                                {
+                                    const float4 xj = xq[(size_t)cj * NA_C + j];
+                                    if (sqr(xi[0] - xj.x) + sqr(xi[1] - xj.y) + sqr(xi[2] - xj.z) < P.rl2) { in_range = true; break; }
+                                }
+                            }
+                            if (!in_range) { mb = 0; }
+                        }
+                    }
+                }
+                const unsigned long long kept = __ballot(mb != 0);
+                if (FILL && mb != 0)
+                {
+                    const int slot = running + __popcll(kept & ((1ull << lane) - 1ull));
+                    nbx_cj4_t *grp = cj4 + base4 + (slot >> 2);
+                    grp->cj[slot & 3] = scj * NSUBC + cjo;
+                    reinterpret_cast<unsigned char *>(&grp->imei[0].imask)[slot & 3] = (unsigned char)mb;
+                    reinterpret_cast<unsigned char *>(&grp->imei[1].imask)[slot & 3] = (unsigned char)mb;
+                    if (central && sci == scj)
+                    {
+                        need_excl[2 * (base4 + (slot >> 2))]     = 1;
+                        need_excl[2 * (base4 + (slot >> 2)) + 1] = 1;
+                    }
+                    npairs += __popc(mb);
+                }
+                running += __popcll(kept);
+            }
+        }
+    }
+    if (!FILL) { if (lane == 0) { ncj[e] = running; } }
+    else
+    {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { npairs += __shfl_xor(npairs, m); }
+        if (lane == 0 && npairs) { atomicAdd(nci_tot, npairs); }
+    }
+}
+
+__global__ void k_groups_of(int n, const int *__restrict__ ncj, int *__restrict__ ncj4)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > n) { return; }
+    ncj4[e] = e < n ? (ncj[e] + 3) >> 2 : 0;
+}
+
+__device__ __forceinline__ int cj_at(const nbx_cj4_t *cj4, int ind) { return cj4[ind >> 2].cj[ind & 3]; }
+
+// set_sci_top_excls, one wave per entry, one lane per i-atom.  APPLY = false marks the
+// (cj4 group, half) pairs that need an exclusion word set; APPLY = true clears the bits (also
+// the j > i masks of the entry's own clusters, set_self_and_newton_excls_supersub).
+template <bool APPLY>
+__global__ void __launch_bounds__(64)
+k_excl(int natoms, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
+       const int *__restrict__ a, const int *__restrict__ cell, const int *__restrict__ excl_index,
+       const int *__restrict__ excl_a, int *__restrict__ need_excl, nbx_excl_t *__restrict__ excl)
+{
+    const int e    = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n    = ncj[e];
+    if (n == 0) { return; }
+    const int  sci     = e / NSHIFT_HALF;
+    const int  ss      = e - sci * NSHIFT_HALF;
+    const bool central = shift_index(c_shift_t[ss][0], c_shift_t[ss][1], c_shift_t[ss][2]) == NBX_CENTRAL;
+    const int  first   = cj4_start[e] * 4, last = first + n - 1;
+
+    if (APPLY && central)
+    {
+        // the entry's own clusters are among its first slots (j super-cells start at i); lane -> (ej, ei >= ej)
+        for (int s = first; s <= min(last, first + NSUBC - 1); s++)
+        {
+            const int cj = cj_at(cj4, s);
+            if ((cj >> 3) != sci) { continue; }
+            const int cjo = cj & 7;
+            if (lane < NA_C * NA_C)
+            {
+                const int ej = lane >> 3, ei = lane & 7;
+                if (ei >= ej)
+                {
+                    const int idx = cj4[s >> 2].imei[ej >> 2].excl_ind;
+                    atomicAnd(&excl[idx].pair[(ej & 3) * NA_C + ei], ~(1u << ((s & 3) * NSUBC + cjo)));
+                }
+            }
+        }
+    }
+    if (excl_index == nullptr) { return; }
+    const int gi = sci * NA_SC + lane;
+    const int ai = a[gi];
+    if (ai < 0) { return; }
+    const int cj_first = cj_at(cj4, first), cj_last = cj_at(cj4, last);
+    const int si = lane >> 3;
+    for (int k = excl_index[ai]; k < excl_index[ai + 1]; k++)
+    {
+        const int aj = excl_a[k];
+        if (aj == ai || aj < 0 || aj >= natoms) { continue; }
+        const int ge = cell[aj];
+        if (ge < 0) { continue; }
+        if (central && ge <= gi) { continue; }
+        const int se = ge >> 3;
+        if (se < cj_first || se > cj_last) { continue; }
+        int lo = first, hi = last + 1, found = -1;
+        while (lo < hi)
+        {
+            const int mid = (lo + hi) >> 1;
+            const int cm  = cj_at(cj4, mid);
+            if (cm == se) { found = mid; break; }
+            if (se < cm) { hi = mid; } else { lo = mid + 1; }
+        }
+        if (found < 0) { continue; }
+        const int      inner_i = lane & 7, inner_e = ge & 7;
+        const unsigned bit     = 1u << ((found & 3) * NSUBC + si);
+        if (cj4[found >> 2].imei[0].imask & bit)
+        {
+            if (!APPLY) { need_excl[2 * (found >> 2) + (inner_e >> 2)] = 1; }
+            else
+            {
+                const int idx = cj4[found >> 2].imei[inner_e >> 2].excl_ind;
+                atomicAnd(&excl[idx].pair[(inner_e & 3) * NA_C + inner_i], ~bit);
+            }
+        }
+    }
+}
+
+// exclusion word sets: entry 0 is the shared all-ones set; flagged (group, half) pairs get
+// 1 + their rank, written into the group and initialised to all ones
+__global__ void k_excl_init(int n2, const int *__restrict__ need_excl, const int *__restrict__ rank, nbx_cj4_t *__restrict__ cj4,
+                            nbx_excl_t *__restrict__ excl)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+    {
+        for (int t = 0; t < 32; t++) { excl[0].pair[t] = 0xffffffffu; }
+    }
+    if (i >= n2 || !need_excl[i]) { return; }
+    const int idx = 1 + rank[i];
+    cj4[i >> 1].imei[i & 1].excl_ind = idx;
+    for (int t = 0; t < 32; t++) { excl[idx].pair[t] = 0xffffffffu; }
+}
+
+// split_sci_entry, one thread per entry.  WRITE = false: nparts[e]; WRITE = true: the entry's
+// nbnxn_sci_t parts at part_start[e].
+template <bool WRITE>
+__global__ void k_split(int nentries, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
+                        const nbx_cj4_t *__restrict__ cj4, int nsp_max, int *__restrict__ nparts,
+                        const int *__restrict__ part_start, nbx_sci_t *__restrict__ sci_out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > nentries) { return; }
+    if (e == nentries) { if (!WRITE) { nparts[e] = 0; } return; }
+    const int n = ncj[e];
+    if (n == 0) { if (!WRITE) { nparts[e] = 0; } return; }
+    const int sci   = e / NSHIFT_HALF;
+    const int ss    = e - sci * NSHIFT_HALF;
+    const int shift = shift_index(c_shift_t[ss][0], c_shift_t[ss][1], c_shift_t[ss][2]);
+    const int start = cj4_start[e], end = start + ((n + 3) >> 2);
+    const int j4len = end - start;
+    int       count = 0;
+    nbx_sci_t *out  = WRITE ? sci_out + part_start[e] : nullptr;
+    auto emit = [&](int s0, int s1) {
+        if (s1 > s0)
+        {
+            if (WRITE) { out[count].sci = sci; out[count].shift = shift; out[count].cj4_ind_start = s0; out[count].cj4_ind_end = s1; }
+            count++;
+        }
+    };
+    if (!(nsp_max > 0 && j4len > 1 && j4len * NSUBC * 4 > nsp_max))
+    {
+        emit(start, end);
+    }
+    else
+    {
+        // the reference's loop keeps all parts and balances the last two at the end; here the
+        // second-to-last one is held back until it is known not to be the one that gets adjusted
+        int  cur_start = start;
+        int  pend0 = 0, pend1 = 0;
+        bool have_pend = false;
+        int  nsp = 0, nsp_sci = 0, nsp_cj4 = 0, nsp_cj4_e = 0;
+        for (int c = start; c < end; c++)
+        {
+            const int nsp_cj4_p = nsp_cj4;
+            nsp_cj4 = __popc(cj4[c].imei[0].imask);
+            if (nsp_cj4 > 0 && nsp + nsp_cj4 > nsp_max)
+            {
+                if (have_pend) { emit(pend0, pend1); }
+                pend0 = cur_start; pend1 = c; have_pend = true;
+                cur_start = c;
+                nsp_sci   = nsp;
+                nsp_cj4_e = nsp_cj4_p;
+                nsp       = 0;
+            }
+            nsp += nsp_cj4;
+        }
+        int last0 = cur_start;
+        if (have_pend && nsp_sci - nsp_cj4_e >= nsp + nsp_cj4_e) { pend1--; last0--; }
+        if (have_pend) { emit(pend0, pend1); }
+        emit(last0, end);
+    }
+    if (!WRITE) { nparts[e] = count; }
+}
+
+// sort_sci key: entries with more cj4 groups first, counts clipped at m
+__global__ void k_sort_keys(int nsci, const nbx_sci_t *__restrict__ sci, int m, unsigned *__restrict__ key)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsci) { return; }
+    key[i] = (unsigned)(m - min(m, sci[i].cj4_ind_end - sci[i].cj4_ind_start));
+}
+
+inline int blocks_for(size_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+} // namespace
+
+struct nbx_search {
+    float    box[3] = {0, 0, 0};
+    int      shp[3] = {1, 1, 1};
+    int      natoms = 0, nc = 0, ncxy = 0, nsubc_tot = 0;
+    float    density = 0;
+    GridDims g;
+    bool     have_columns = false, have_grid = false;
+    // gridding
+    Buf<int>                cxy_na, ncz, cxy_ind, atom_start, val_in, sorted_atom, a, cell, nsubc, counters;
+    Buf<unsigned long long> key_in, key_out;
+    Buf<float>              bb, bbcz;
+    // list
+    Buf<int>        ncj, ncj4_e, cj4_start, need_excl, excl_rank, nparts, part_start;
+    Buf<nbx_cj4_t>  cj4;
+    Buf<nbx_excl_t> excl;
+    Buf<nbx_sci_t>  sci_a, sci_b;
+    Buf<unsigned>   skey_in, skey_out;
+    nbx_prim_tmp    tmp;
+};
+
+nbx_search *nbx_search_create() { return new nbx_search(); }
+
+void nbx_search_destroy(nbx_search *s)
+{
+    if (!s) { return; }
+    s->cxy_na.release(); s->ncz.release(); s->cxy_ind.release(); s->atom_start.release(); s->val_in.release();
+    s->sorted_atom.release(); s->a.release(); s->cell.release(); s->nsubc.release(); s->counters.release();
+    s->key_in.release(); s->key_out.release(); s->bb.release(); s->bbcz.release();
+    s->ncj.release(); s->ncj4_e.release(); s->cj4_start.release(); s->need_excl.release(); s->excl_rank.release();
+    s->nparts.release(); s->part_start.release(); s->cj4.release(); s->excl.release(); s->sci_a.release(); s->sci_b.release();
+    s->skey_in.release(); s->skey_out.release();
+    nbx_prim_free(s->tmp);
+    delete s;
+}
+
+const char *nbx_search_error() { return g_err.c_str(); }
+
+int nbx_search_grid_columns(nbx_search *s, hipStream_t st, const float box[3], const int pbc_shift_dim[3], int n,
+                            const float *d_x, float atom_density)
+{
+    if (!s) { return sfail("null search handle"); }
+    if (n <= 0 || !d_x) { return sfail("put_on_grid needs atoms"); }
+    for (int d = 0; d < 3; d++)
+    {
+        if (!(box[d] > 0)) { return sfail("box[%d] = %g must be > 0", d, box[d]); }
+        s->box[d] = box[d];
+        s->shp[d] = pbc_shift_dim[d] ? 1 : 0;
+    }
+    s->have_columns = s->have_grid = false;
+    s->natoms = n;
+    // set_grid_size_xy (:433-486): columns of 2x2 roughly cubic sub-cells, as the host builder sizes them
+    if (atom_density <= 0) { atom_density = std::max(n, 1) / (box[0] * box[1] * box[2]); }
+    s->density = atom_density;
+    GridDims &g = s->g;
+    g.c0[0] = g.c0[1] = g.c0[2] = 0;
+    if (n > NA_SC)
+    {
+        const float tlen = std::cbrt(NA_C / atom_density);
+        g.ncx = std::max(1, (int)(box[0] / (tlen * 2)));
+        g.ncy = std::max(1, (int)(box[1] / (tlen * 2)));
+    }
+    else { g.ncx = 1; g.ncy = 1; }
+    g.sx = box[0] / g.ncx; g.inv_sx = 1 / g.sx;
+    g.sy = box[1] / g.ncy; g.inv_sy = 1 / g.sy;
+    const int ncxy = g.ncx * g.ncy;
+    s->ncxy = ncxy;
+
+    if (s->cxy_na.reserve(ncxy + 1) || s->ncz.reserve(ncxy + 1) || s->cxy_ind.reserve(ncxy + 1) || s->atom_start.reserve(ncxy + 1)
+        || s->key_in.reserve(n) || s->key_out.reserve(n) || s->val_in.reserve(n) || s->sorted_atom.reserve(n)
+        || s->counters.reserve(8)) { return 1; }
+    S_TRY(hipMemsetAsync(s->cxy_na.p, 0, (ncxy + 1) * sizeof(int), st));
+    S_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(int), st));
+    hipLaunchKernelGGL(k_columns, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, d_x, g, s->cxy_na.p, s->key_in.p, s->val_in.p);
+    hipLaunchKernelGGL(k_column_cells, dim3(blocks_for(ncxy + 1, 256)), dim3(256), 0, st, ncxy, s->cxy_na.p, s->ncz.p);
+    S_TRY(hipGetLastError());
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncz.p, s->cxy_ind.p, ncxy + 1, st));
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->cxy_na.p, s->atom_start.p, ncxy + 1, st));
+    int col_bits = 1;
+    while ((1 << col_bits) < ncxy) { col_bits++; }
+    S_TRY(nbx_prim_sort_u64_int(s->tmp, s->key_in.p, s->key_out.p, s->val_in.p, s->sorted_atom.p, n, 32 + col_bits, st));
+    int nc = 0;
+    S_TRY(hipMemcpyAsync(&nc, s->cxy_ind.p + ncxy, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipStreamSynchronize(st));
+    s->nc = nc;
+    s->have_columns = true;
+    return 0;
+}
+
+int nbx_search_natoms_padded(const nbx_search *s) { return s && s->have_columns ? s->nc * NA_SC : -1; }
+
+int nbx_search_grid_fill(nbx_search *s, hipStream_t st, const float *d_x, const float *d_q, const int *d_type,
+                         int ntype_with_dummy, float4 *d_xq, int *d_type_out)
+{
+    if (!s || !s->have_columns) { return sfail("grid_fill before grid_columns"); }
+    const size_t npad = (size_t)s->nc * NA_SC;
+    if (s->a.reserve(npad) || s->cell.reserve(s->natoms) || s->nsubc.reserve(s->nc) || s->bb.reserve((size_t)s->nc * NSUBC * 6)
+        || s->bbcz.reserve((size_t)s->nc * 2)) { return 1; }
+    hipLaunchKernelGGL(k_supercells, dim3(s->nc), dim3(64), 0, st, s->nc, s->ncxy, s->g, s->cxy_ind.p, s->cxy_na.p, s->atom_start.p,
+                       s->sorted_atom.p, d_x, d_q, d_type, ntype_with_dummy - 1, s->a.p, s->cell.p, d_xq, d_type_out, s->bb.p,
+                       s->bbcz.p, s->nsubc.p, s->counters.p);
+    S_TRY(hipGetLastError());
+    s->have_grid = true;
+    s->nsubc_tot = -1;   // read back when the list needs it
+    return 0;
+}
+
+const int *nbx_search_atom_order(const nbx_search *s) { return s->a.p; }
+const int *nbx_search_cell_index(const nbx_search *s) { return s->cell.p; }
+
+int nbx_search_grid_info(const nbx_search *s, int *ncx, int *ncy, int *nc)
+{
+    if (!s || !s->have_columns) { return sfail("no grid"); }
+    *ncx = s->g.ncx; *ncy = s->g.ncy; *nc = s->nc;
+    return 0;
+}
+
+int nbx_search_download_grid(const nbx_search *s, hipStream_t st, int *a, int *cell, float *bb, float *bbcz, int *nsubc)
+{
+    if (!s || !s->have_grid) { return sfail("no grid"); }
+    if (a) { S_TRY(hipMemcpyAsync(a, s->a.p, (size_t)s->nc * NA_SC * sizeof(int), hipMemcpyDeviceToHost, st)); }
+    if (cell) { S_TRY(hipMemcpyAsync(cell, s->cell.p, (size_t)s->natoms * sizeof(int), hipMemcpyDeviceToHost, st)); }
+    if (bb) { S_TRY(hipMemcpyAsync(bb, s->bb.p, (size_t)s->nc * NSUBC * 6 * sizeof(float), hipMemcpyDeviceToHost, st)); }
+    if (bbcz) { S_TRY(hipMemcpyAsync(bbcz, s->bbcz.p, (size_t)s->nc * 2 * sizeof(float), hipMemcpyDeviceToHost, st)); }
+    if (nsubc) { S_TRY(hipMemcpyAsync(nsubc, s->nsubc.p, (size_t)s->nc * sizeof(int), hipMemcpyDeviceToHost, st)); }
+    S_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+namespace {
+
+// get_nsubpair_max (nbnxn_search.c:4324-4408), single-grid estimate, as in the host builder
+int nsubpair_max(const nbx_search &s, float rlist, int min_ci_balanced)
+{
+    if (min_ci_balanced <= 0 || s.nc >= min_ci_balanced || s.nc == 0) { return -1; }
+    double ls[3];
+    ls[0] = s.box[0] / (s.g.ncx * 2);
+    ls[1] = s.box[1] / (s.g.ncy * 2);
+    ls[2] = s.box[2] * s.g.ncx * s.g.ncy / (s.nc * 2.0);
+    const double diag2 = ls[0] * ls[0] + ls[1] * ls[1] + ls[2] * ls[2];
+    const float  f     = (NA_C - 1.0f) / NA_C;
+    const double r_eff = rlist + 0.5 * (f * f) * std::sqrt(diag2 / 3);
+    double       vol   = ls[0] * ls[1] * ls[2];
+    vol += (ls[0] * ls[1] + ls[0] * ls[2] + ls[1] * ls[2]) * r_eff;
+    vol += 2 * (ls[0] + ls[1] + ls[2]) * 0.25 * M_PI * r_eff * r_eff;
+    vol += 0.5 * 4.0 / 3.0 * M_PI * r_eff * r_eff * r_eff;
+    const double nsp_est = s.nsubc_tot * vol * s.density / NA_C;
+    const int    nsp     = std::max(1, (int)(nsp_est / min_ci_balanced + 0.5));
+    return nsp + NSUBC * 4 / 2;
+}
+
+} // namespace
+
+int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min_ci_balanced, const int *d_excl_index,
+                             const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out)
+{
+    if (!s || !s->have_grid) { return sfail("no grid: put the atoms on the grid first"); }
+    if (!(rlist > 0)) { return sfail("rlist must be > 0"); }
+    for (int d = 0; d < 3; d++)
+    {
+        if (s->shp[d] && s->box[d] < 2 * rlist)
+        {
+            return sfail("box[%d] = %g is shorter than 2*rlist = %g: more than one periodic image in range", d, s->box[d], 2 * rlist);
+        }
+    }
+    ListParams P;
+    P.g = s->g; P.nc = s->nc;
+    for (int d = 0; d < 3; d++) { P.box[d] = s->box[d]; P.shp[d] = s->shp[d]; }
+    P.rlist = rlist;
+    P.rl2   = rlist * rlist;
+    {
+        // boundingbox_only_distance2 (:4721-4757), float arithmetic as in the host builder
+        const float bbx = 0.5f * (s->g.sx + s->g.sx) / 2, bby = 0.5f * (s->g.sy + s->g.sy) / 2;
+        const float r   = std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby));
+        P.rbb2 = r * r;
+    }
+    const int nent = s->nc * NSHIFT_HALF;
+    int      *cnt  = s->counters.p;   // [0] nsubc_tot (from gridding), [1] nci_tot
+
+    if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)
+        || s->part_start.reserve(nent + 1)) { return 1; }
+    S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));
+    hipLaunchKernelGGL((k_list<false>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, d_xq, s->ncj.p,
+                       (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)nullptr);
+    hipLaunchKernelGGL(k_groups_of, dim3(blocks_for(nent + 1, 256)), dim3(256), 0, st, nent, s->ncj.p, s->ncj4_e.p);
+    S_TRY(hipGetLastError());
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncj4_e.p, s->cj4_start.p, nent + 1, st));
+    int h1[2] = {0, 0};
+    S_TRY(hipMemcpyAsync(&h1[0], s->cj4_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&h1[1], cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipStreamSynchronize(st));
+    const int ncj4 = h1[0];
+    s->nsubc_tot   = h1[1];
+    const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced);
+
+    if (s->cj4.reserve((size_t)ncj4 + 1) || s->need_excl.reserve(2 * (size_t)ncj4 + 1) || s->excl_rank.reserve(2 * (size_t)ncj4 + 1)) { return 1; }
+    S_TRY(hipMemsetAsync(s->cj4.p, 0, ((size_t)ncj4 + 1) * sizeof(nbx_cj4_t), st));
+    S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
+    hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, d_xq, s->ncj.p,
+                       s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1));
+    hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+                       d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
+    hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, s->ncj.p, s->cj4_start.p, s->cj4.p,
+                       nsp_max, s->nparts.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
+    S_TRY(hipGetLastError());
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->need_excl.p, s->excl_rank.p, 2 * ncj4 + 1, st));
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->nparts.p, s->part_start.p, nent + 1, st));
+    int h2[3] = {0, 0, 0};
+    S_TRY(hipMemcpyAsync(&h2[0], s->excl_rank.p + 2 * ncj4, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&h2[1], s->part_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&h2[2], cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipStreamSynchronize(st));
+    const int nexcl = 1 + h2[0], nsci = h2[1], nci_tot = h2[2];
+
+    if (s->excl.reserve(nexcl) || s->sci_a.reserve((size_t)nsci + 1) || s->sci_b.reserve((size_t)nsci + 1) || s->skey_in.reserve((size_t)nsci + 1)
+        || s->skey_out.reserve((size_t)nsci + 1)) { return 1; }
+    hipLaunchKernelGGL(k_excl_init, dim3(blocks_for(2 * (size_t)ncj4 + 1, 256)), dim3(256), 0, st, 2 * ncj4, s->need_excl.p, s->excl_rank.p,
+                       s->cj4.p, s->excl.p);
+    hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+                       d_excl_index, d_excl_a, (int *)nullptr, s->excl.p);
+    hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, s->ncj.p, s->cj4_start.p, s->cj4.p,
+                       nsp_max, (int *)nullptr, s->part_start.p, s->sci_a.p);
+    S_TRY(hipGetLastError());
+    const nbx_sci_t *sci_final = s->sci_a.p;
+    // sort_sci (:5517-5580): only when the groups outnumber the entries
+    if (ncj4 > nsci && nsci > 0)
+    {
+        const int m = (int)(2 * (size_t)ncj4 / (size_t)nsci);
+        int       bits = 1;
+        while ((1 << bits) <= m) { bits++; }
+        hipLaunchKernelGGL(k_sort_keys, dim3(blocks_for(nsci, 256)), dim3(256), 0, st, nsci, s->sci_a.p, m, s->skey_in.p);
+        S_TRY(hipGetLastError());
+        S_TRY(nbx_prim_sort_u32_sci(s->tmp, s->skey_in.p, s->skey_out.p, s->sci_a.p, s->sci_b.p, nsci, bits, st));
+        sci_final = s->sci_b.p;
+    }
+    out->nsci = nsci; out->ncj4 = ncj4; out->nexcl = nexcl; out->nci_tot = nci_tot;
+    out->sci = sci_final; out->cj4 = s->cj4.p; out->excl = s->excl.p;
+    return 0;
+}

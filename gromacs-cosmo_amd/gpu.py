@@ -91,6 +91,10 @@ def load():
     lib.nbnxn_hip_set_vdw_modifier_flat.argtypes = [vp, ci] + [cf] * 8
     lib.nbnxn_hip_set_ljpme_flat.argtypes = [vp, ci, cf, cf, vp]
     lib.nbnxn_hip_download_coulomb_tab.argtypes = [vp, vp, ci, C.POINTER(ci), C.POINTER(cf)]
+    lib.nbnxn_hip_put_on_grid.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, cf]
+    lib.nbnxn_hip_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci]
+    lib.nbnxn_hip_download_grid.argtypes = [vp] + [vp] * 8
+    lib.nbnxn_hip_download_pairlist.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.nbnxn_hip_set_atom_order.argtypes = [vp, ci, vp, vp]
     lib.nbnxn_hip_upload_xq_flat.argtypes = [vp, vp, ci]
     lib.nbnxn_hip_copy_x_to_xq.argtypes = [vp, vp, ci, ci]
@@ -151,6 +155,55 @@ class NbnxnHip:
             comb = nbfp_comb(nbfp, ntype, ip.ljpme_comb_rule)
             self._chk(self.lib.nbnxn_hip_set_ljpme_flat(self.h, ip.ljpme_comb_rule, ip.ewaldcoeff_lj, ip.sh_lj_ewald,
                                                         abi.ptr(comb)))
+
+    # ---- pair search on the device ----
+    def put_on_grid(self, box, x, type_, q, pbc_shift_dim=None, atom_density=0.0):
+        """nbnxn_put_on_grid + nbnxn_atomdata_set + init_atomdata + copy_x on the device.  x: numpy
+        [n,3] or an object with __cuda_array_interface__ (device array).  Returns the padded atom count."""
+        box = np.ascontiguousarray(box, dtype=np.float32)
+        type_ = np.ascontiguousarray(type_, dtype=np.int32)
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        pbc = None if pbc_shift_dim is None else np.ascontiguousarray(pbc_shift_dim, dtype=np.int32)
+        if hasattr(x, "__cuda_array_interface__"):
+            xp, on_dev, n = C.c_void_p(x.__cuda_array_interface__["data"][0]), 1, x.__cuda_array_interface__["shape"][0]
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            xp, on_dev, n = abi.ptr(x), 0, len(x)
+        assert len(type_) == n and len(q) == n
+        self._chk(self.lib.nbnxn_hip_put_on_grid(self.h, abi.ptr(box), abi.ptr(pbc), n, xp, on_dev, abi.ptr(type_), abi.ptr(q),
+                                                 atom_density))
+        dims = np.zeros(4, dtype=np.int32)
+        self._chk(self.lib.nbnxn_hip_download_grid(self.h, abi.ptr(dims), None, None, None, None, None, None, None))
+        self.natoms = int(dims[3])
+        self.natoms_real = n
+        return self.natoms
+
+    def make_pairlist(self, rlist, excl_index=None, excl_a=None, min_ci_balanced=0, iloc=abi.LOCAL):
+        if excl_index is not None:
+            excl_index = np.ascontiguousarray(excl_index, dtype=np.int32)
+            excl_a = np.ascontiguousarray(excl_a, dtype=np.int32)
+        self._chk(self.lib.nbnxn_hip_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a), min_ci_balanced))
+
+    def download_grid(self):
+        dims = np.zeros(4, dtype=np.int32)
+        self._chk(self.lib.nbnxn_hip_download_grid(self.h, abi.ptr(dims), None, None, None, None, None, None, None))
+        ncx, ncy, nc, npad = (int(v) for v in dims)
+        out = dict(ncx=ncx, ncy=ncy, nc=nc, a=np.zeros(npad, np.int32), cell=np.zeros(self.natoms_real, np.int32),
+                   bb=np.zeros((nc * 8, 6), np.float32), bbcz=np.zeros((nc, 2), np.float32), nsubc=np.zeros(nc, np.int32),
+                   xq=np.zeros((npad, 4), np.float32), type=np.zeros(npad, np.int32))
+        self._chk(self.lib.nbnxn_hip_download_grid(self.h, None, abi.ptr(out["a"]), abi.ptr(out["cell"]), abi.ptr(out["bb"]),
+                                                   abi.ptr(out["bbcz"]), abi.ptr(out["nsubc"]), abi.ptr(out["xq"]), abi.ptr(out["type"])))
+        return out
+
+    def download_pairlist(self, iloc=abi.LOCAL):
+        from .host import PairList
+        cnt = np.zeros(4, dtype=np.int32)
+        self._chk(self.lib.nbnxn_hip_download_pairlist(self.h, iloc, abi.ptr(cnt), None, None, None))
+        sci = np.zeros(int(cnt[0]), dtype=abi.sci_dtype)
+        cj4 = np.zeros(int(cnt[1]), dtype=abi.cj4_dtype)
+        excl = np.zeros(int(cnt[2]), dtype=abi.excl_dtype)
+        self._chk(self.lib.nbnxn_hip_download_pairlist(self.h, iloc, None, abi.ptr(sci), abi.ptr(cj4), abi.ptr(excl)))
+        return PairList(sci, cj4, excl, int(cnt[3]), 0.0)
 
     def coulomb_tab(self):
         """(table [size] float32, scale) of the tabulated Ewald flavour, in the reference's units."""

@@ -408,6 +408,37 @@ int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, vo
  * resident callers that reduce them on the device (the multi-GPU all-reduce). */
 int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, int *stride);
 
+/* ------------------------------------------------------------------------------------
+ * Pair search on the device (home zone, local list).  The two calls stand where the
+ * reference's host code has nbnxn_put_on_grid (nbnxn_search.c:1777, called at sim_util.c:982)
+ * + nbnxn_atomdata_set (nbnxn_atomdata.c:1094) + nbnxn_cuda_init_atomdata
+ * (nbnxn_cuda_data_mgmt.h:81), and nbnxn_make_pairlist (nbnxn_search.c:5583, sim_util.c:1022)
+ * + nbnxn_cuda_init_pairlist (nbnxn_cuda_data_mgmt.h:75): atoms and list never visit the host.
+ * ---------------------------------------------------------------------------------- */
+
+/* Grids natoms atoms of a rectangular box [0, box) into columns / super-cells / clusters exactly
+ * as the host-side builder (include/nbnxn_host.h) does, and fills the module's grid-ordered
+ * coordinates+charges (with fillers), types (dummy type = ntype - 1 of init_const), atom-order
+ * arrays (as nbnxn_hip_set_atom_order would) and shift vectors.  x [natoms][3] may be a host or a
+ * device array; type and q are host arrays in caller order; pbc_shift_dim NULL = periodic in
+ * x, y and z; atom_density <= 0 = natoms / volume.  Invalidates the lists.  Call after init_const. */
+int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
+                          int x_on_device, const int *type, const float *q, float atom_density);
+
+/* Builds the local list for the atoms gridded by nbnxn_hip_put_on_grid and installs it as
+ * nbnxn_hip_init_pairlist would (its first kernel prunes it).  excl_index [natoms+1] / excl_a:
+ * topology exclusions in caller atom numbering (t_blocka index / a), NULL for none;
+ * min_ci_balanced as for nbnxn_make_pairlist (nbnxn_hip_min_ci_balanced()).  iloc must be
+ * NBX_LOCAL: halo zones stay with the host-side builder. */
+int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced);
+
+/* Verification aids: the device grid (dims = {ncx, ncy, number of super-cells, padded atoms};
+ * a [padded], cell [natoms], bb [clusters][6] = lo xyz, hi xyz, bbcz [super-cells][2],
+ * nsubc [super-cells], xq [padded][4], type [padded]; any pointer may be NULL) and the list
+ * installed for iloc (counts = {nsci, ncj4, nexcl, nci_tot}; call once with NULL arrays for the sizes). */
+int nbnxn_hip_download_grid(nbnxn_hip_ptr_t nb, int *dims, int *a, int *cell, float *bb, float *bbcz, int *nsubc, float *xq, int *type);
+int nbnxn_hip_download_pairlist(nbnxn_hip_ptr_t nb, int iloc, int *counts, nbx_sci_t *sci, nbx_cj4_t *cj4, nbx_excl_t *excl);
+
 /* Verification aid for the tabulated Ewald flavour: size and scale of the force table this
  * module generated (init_ewald_coulomb_force_table, nbnxn_cuda_data_mgmt.cu:120-183:
  * 1536 points, scale = (size - 2) / rcoulomb) and, when tab != NULL, its entries in the

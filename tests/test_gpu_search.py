@@ -1,0 +1,168 @@
+"""Pair search on the device (nbnxn_put_on_grid + nbnxn_make_pairlist) against the
+host-side builder (gromacs-cosmo_amd/csrc/nbnxn_host.cpp, itself checked against brute force in
+tests/test_host_list.py): the grid order, the grid-ordered atom data and the list must be THE SAME,
+index for index and bit for bit, and the forces computed from the device-built list must meet the
+kernel's parity bar against the oracle."""
+import numpy as np
+import pytest
+
+import gromacs_cosmo_amd as g
+from gromacs_cosmo_amd import abi
+import oracle as O
+from util import FORCE_RTOL, ENERGY_RTOL, relrms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nb():
+    h = g.gpu.NbnxnHip(0)
+    yield h
+    h.close()
+
+
+def _excl_words(pl):
+    """[ncj4, 2, 32] exclusion words each (group, half) points to"""
+    return pl.excl["pair"][pl.cj4["imei"]["excl_ind"]]
+
+
+def _assert_same_list(dev, host):
+    assert (dev.nsci, dev.ncj4, dev.nexcl, dev.nci_tot) == (host.nsci, host.ncj4, host.nexcl, host.nci_tot)
+    assert np.array_equal(dev.sci, host.sci)
+    assert np.array_equal(dev.cj4["imei"]["imask"], host.cj4["imei"]["imask"])
+    used = ((host.cj4["imei"]["imask"][:, 0, None] >> (8 * np.arange(4))) & 0xff) != 0
+    assert np.array_equal(dev.cj4["cj"][used], host.cj4["cj"][used])
+    # exclusion sets are numbered in a different order on the device; what they hold must agree
+    assert np.array_equal(_excl_words(dev), _excl_words(host))
+    assert np.all(dev.excl["pair"][0] == 0xffffffff)
+
+
+def _device_search(nb, s, ip, mcb):
+    nb.init_const(ip, s.ntype + 1, s.nbfp())
+    npad = nb.put_on_grid(s.box, s.x, s.type, s.q)
+    nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, mcb)
+    return npad
+
+
+def _forces_resident(nb, flags):
+    f = np.zeros((nb.natoms, 3), dtype=np.float32)
+    e_lj, e_el = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    fsh = np.zeros((abi.SHIFTS, 3), dtype=np.float32)
+    nb.clear_outputs(flags | abi.FORCE_VIRIAL)
+    nb.launch_kernel_resident(flags)
+    nb.launch_cpyback(f, flags)
+    nb.wait_gpu(flags, abi.LOCAL, e_lj, e_el, fsh)
+    return f, float(e_lj[0]), float(e_el[0])
+
+
+CASES = [
+    ("water 5k rf", lambda: g.system.water_box(2, 2, 2), lambda: g.system.reaction_field(0.9), 0),
+    ("water 5k ewald split", lambda: g.system.water_box(2, 2, 2, model="spce"), lambda: g.system.ewald(0.9, rlist=1.0), 600),
+    ("chains 3k", lambda: g.system.lj_chain_mixture(3000), lambda: g.system.reaction_field(0.9), 0),
+    ("chains 6k split", lambda: g.system.lj_chain_mixture(6000, ntype=8, seed=11), lambda: g.system.ewald(0.9, rlist=1.05), 2000),
+    ("water 97k", lambda: g.system.water_box(5, 5, 6), lambda: g.system.reaction_field(1.0), None),
+]
+
+
+@pytest.mark.parametrize("name,make_system,make_ip,mcb", CASES, ids=[c[0] for c in CASES])
+def test_device_grid_and_list_equal_the_host_builders(nb, name, make_system, make_ip, mcb):
+    s, ip = make_system(), make_ip()
+    mcb = nb.min_ci_balanced() if mcb is None else mcb
+    p = g.workload.prepare(s, ip, mcb)
+    npad = _device_search(nb, s, ip, mcb)
+    assert npad == p.natoms
+    grid = nb.download_grid()
+    assert (grid["ncx"], grid["ncy"]) == p.host.ncolumns() and grid["nc"] * 64 == npad
+    assert np.array_equal(grid["a"], p.host.atom_order())
+    assert np.array_equal(grid["cell"], p.host.cell_index())
+    assert np.array_equal(grid["xq"].view(np.uint32), p.xq.view(np.uint32))      # fillers included, bit for bit
+    assert np.array_equal(grid["type"], p.type)
+    # every cluster's box holds its atoms
+    real = grid["a"].reshape(-1, 8) >= 0
+    xc = grid["xq"][:, :3].reshape(-1, 8, 3)
+    for cl in np.flatnonzero(real.any(axis=1))[::97]:
+        pts = xc[cl][real[cl]]
+        assert np.array_equal(grid["bb"][cl, :3], pts.min(axis=0)) and np.array_equal(grid["bb"][cl, 3:], pts.max(axis=0))
+    dev = nb.download_pairlist()
+    _assert_same_list(dev, p.pl)
+    if mcb:
+        assert dev.nsci > grid["nc"]          # the balancing split really happened
+    # and the kernel on the device-built list, coordinates never having left the device
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    f, elj, eel = _forces_resident(nb, abi.FORCE_VIRIAL)
+    assert relrms(f, o["f"]) < FORCE_RTOL
+    assert abs(elj - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"]) and abs(eel - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"])
+    # forces back in caller order through the device-side atom order
+    fa = np.zeros((s.natoms, 3), dtype=np.float32)
+    nb.add_f(fa)
+    fo = np.zeros((s.natoms, 3), dtype=np.float32)
+    p.host.add_f(np.asarray(o["f"], dtype=np.float32), fo)
+    assert relrms(fa, fo) < FORCE_RTOL
+
+
+def test_device_search_edge_cases(nb):
+    """fewer atoms than one super-cell, a ragged last cluster, no exclusions, a non-periodic dimension"""
+    rng = np.random.default_rng(5)
+    ip = g.system.reaction_field(0.9)
+    for n, pbc in ((37, (1, 1, 1)), (64, (1, 1, 1)), (1001, (1, 1, 1)), (1001, (1, 1, 0))):
+        box = np.array([3.0, 3.2, 3.4], dtype=np.float32)
+        # jittered lattice (no overlapping atoms), a random subset of its sites
+        sites = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(11), indexing="ij"), -1).reshape(-1, 3)
+        x = ((sites[rng.permutation(len(sites))[:n]] + 0.5 + rng.uniform(-0.15, 0.15, (n, 3))) * (box / (10, 10, 11))).astype(np.float32)
+        x[10:15, 2] = x[15:20, 2]                   # equal z: ties go by atom index
+        x[3, 0] = 0.0                               # on the lower edge of the first column
+        x[4, :2] = np.nextafter(box[:2], 0)         # the last representable point inside the last column
+        typ = rng.integers(0, 2, n).astype(np.int32)
+        q = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+        nbfp = np.zeros((3, 3, 2), dtype=np.float32)
+        nbfp[:2, :2, 0], nbfp[:2, :2, 1] = 6 * 2.6e-3, 12 * 2.6e-6
+        h = g.host.NbnxnHost(box, pbc)
+        h.put_on_grid(0, (0, 0, 0), box, 0, x)
+        xq, t = h.set_atomdata(3, typ, q)
+        h.copy_x_to_xq(x, xq)
+        pl = h.make_pairlist(abi.LOCAL, ip.rlist, xq, None, None, 0)
+        nb.init_const(ip, 3, nbfp)
+        assert nb.put_on_grid(box, x, typ, q, pbc_shift_dim=pbc) == len(xq)
+        nb.make_pairlist(ip.rlist, None, None, 0)
+        grid = nb.download_grid()
+        assert np.array_equal(grid["a"], h.atom_order()) and np.array_equal(grid["xq"].view(np.uint32), xq.view(np.uint32))
+        _assert_same_list(nb.download_pairlist(), pl)
+        o = O.kernel_gpu_list(xq, t, 3, nbfp, h.shift_vec(), pl, ip)
+        f, elj, eel = _forces_resident(nb, abi.FORCE_VIRIAL)
+        assert relrms(f, o["f"]) < FORCE_RTOL
+
+
+def test_device_search_follows_moving_atoms(nb):
+    """a second search on displaced coordinates given as a DEVICE array (the MD loop's case)"""
+    import torch
+    s = g.system.water_box(2, 2, 2)
+    ip = g.system.reaction_field(0.9)
+    _device_search(nb, s, ip, 0)
+    rng = np.random.default_rng(9)
+    x2 = np.mod(s.x + rng.normal(0, 0.05, s.x.shape), s.box).astype(np.float32)
+    xd = torch.from_numpy(x2).cuda()
+    nb.put_on_grid(s.box, xd, s.type, s.q)
+    nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0)
+    import dataclasses
+    s2 = dataclasses.replace(s, x=x2)
+    p = g.workload.prepare(s2, ip, 0)
+    assert np.array_equal(nb.download_grid()["a"], p.host.atom_order())
+    _assert_same_list(nb.download_pairlist(), p.pl)
+
+
+def test_device_search_refusals(nb):
+    s = g.system.water_box(1, 1, 1)
+    ip = g.system.reaction_field(0.9)
+    nb.init_const(ip, s.ntype + 1, s.nbfp())
+    nb.put_on_grid(s.box, s.x, s.type, s.q)
+    with pytest.raises(RuntimeError):
+        nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0, iloc=abi.NONLOCAL)     # halo zones: host builder
+    with pytest.raises(RuntimeError):
+        nb.make_pairlist(1.0, s.excl_index, s.excl_a, 0)                             # box 1.86 < 2 rlist
+    with pytest.raises(RuntimeError):
+        nb.put_on_grid(s.box, s.x, s.type + 7, s.q)                                  # types outside the LJ table
+    # a host-side init_atomdata invalidates the device grid
+    p = g.workload.prepare(s, ip, 0)
+    g.workload.upload(nb, p, ip)
+    with pytest.raises(RuntimeError):
+        nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0)

@@ -1,9 +1,14 @@
 """SlabRun (the bench.py --gpus N path) rehearsed on ONE GPU: two ranks share cuda:0 and talk
 over gloo (dd.py stages device tensors through the host for gloo; RCCL needs one GPU per
 rank).  Covers what the CPU test cannot: the HIP module's buffers aliased as torch tensors,
-local + non-local lists on two HIP streams, the resident per-step sequence."""
+local + non-local lists on two HIP streams, the resident per-step sequence.
+
+Collected after the single-process GPU tests on purpose (file name): it is the only GPU test that
+starts other processes, and it watches them with a deadline of its own, so that a stuck rank ends
+as a failure with the ranks' stacks on record (gpurun_out/dd_hang_rank*.txt) instead of a hang."""
 import os
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -11,18 +16,28 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_dd_cpu import _free_port  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
 
+DEADLINE_S = 100
+
+
 def _worker(rank, world, port, model, ret):
+    import datetime
+    import faulthandler
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    hang_log = open(os.path.join(ROOT, "gpurun_out", f"dd_hang_rank{rank}.txt"), "w")
+    faulthandler.dump_traceback_later(DEADLINE_S - 20, file=hang_log, exit=False)
     import gromacs_cosmo_amd as g
     from gromacs_cosmo_amd import abi, dd
     import oracle as O
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60))
     try:
         torch.cuda.set_device(0)
         ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
@@ -45,13 +60,25 @@ def _worker(rank, world, port, model, ret):
                          e_lj=float(e[0]), e_el=float(e[1]), e_lj_ref=float(o["Vvdw"]), e_el_ref=float(o["Vc"]))
     finally:
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
+        hang_log.close()
+        if os.path.getsize(hang_log.name) == 0:
+            os.remove(hang_log.name)
 
 
 @pytest.mark.parametrize("model", ["spc", "spce"])
 def test_slabrun_two_ranks_one_gpu(model):
     with mp.Manager() as m:
         ret = m.dict()
-        mp.spawn(_worker, args=(2, _free_port(), model, ret), nprocs=2, join=True)
+        ctx = mp.spawn(_worker, args=(2, _free_port(), model, ret), nprocs=2, join=False)
+        t0 = time.time()
+        while not ctx.join(timeout=2):
+            if time.time() - t0 > DEADLINE_S:
+                alive = [i for i, p in enumerate(ctx.processes) if p.is_alive()]
+                for p in ctx.processes:
+                    if p.is_alive():
+                        p.kill()
+                pytest.fail(f"ranks {alive} still running after {DEADLINE_S} s; their stacks are in gpurun_out/dd_hang_rank*.txt")
         res = [ret[r] for r in range(2)]
     for r in res:
         assert r["err"] < 1e-5, r
