@@ -144,6 +144,7 @@ struct nbnxn_hip {
     // device-side pair search (nbnxn_hip_put_on_grid / nbnxn_hip_make_pairlist), created on first use
     nbx_search   *search = nullptr;
     bool          grid_on_device = false;   // the atom arrays in use came from nbnxn_hip_put_on_grid
+    bool          excl_held = false;        // d_excl_index / d_excl_a hold a topology
     DevBuf<int>   d_type_in, d_excl_index, d_excl_a;   // caller-order types; topology exclusions (CSR)
     DevBuf<float> d_q_in;
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
@@ -1139,9 +1140,15 @@ int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_
 {
     if (check_handle(nb)) { return 1; }
     if (!nb->have_const) { return nbx_fail("put_on_grid before init_const (the number of atom types comes from there)"); }
-    if (natoms <= 0 || !box || !x || !type || !q) { return nbx_fail("put_on_grid: missing atoms, box, types or charges"); }
+    if (natoms <= 0 || !box || !x) { return nbx_fail("put_on_grid: missing atoms or box"); }
+    if ((type == nullptr) != (q == nullptr)) { return nbx_fail("put_on_grid: types and charges come together"); }
+    // the topology does not change between searches: NULL type / q reuse the arrays of the last call
+    if (!type && ((int)nb->d_type_in.n != natoms || (int)nb->d_q_in.n != natoms))
+    {
+        return nbx_fail("put_on_grid without types / charges, but none are held for %d atoms", natoms);
+    }
     HIP_TRY(hipSetDevice(nb->device));
-    for (int i = 0; i < natoms; i++)
+    for (int i = 0; type && i < natoms; i++)
     {
         if (type[i] < 0 || type[i] >= nb->ntype - 1) { return nbx_fail("atom %d has type %d outside [0,%d)", i, type[i], nb->ntype - 1); }
     }
@@ -1149,15 +1156,18 @@ int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_
     nb->grid_on_device = false;
     hipStream_t st = nb->stream[0];
     const float *d_x = x;
-    if (dev_reserve(nb->d_type_in, natoms) || dev_reserve(nb->d_q_in, natoms)) { return 1; }
+    if (type && (dev_reserve(nb->d_type_in, natoms) || dev_reserve(nb->d_q_in, natoms))) { return 1; }
     if (!x_on_device)
     {
         if (dev_reserve(nb->d_x, (size_t)natoms * 3)) { return 1; }
         HIP_TRY(hipMemcpyAsync(nb->d_x.p, x, (size_t)natoms * 3 * sizeof(float), hipMemcpyHostToDevice, st));
         d_x = nb->d_x.p;
     }
-    HIP_TRY(hipMemcpyAsync(nb->d_type_in.p, type, (size_t)natoms * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(nb->d_q_in.p, q, (size_t)natoms * sizeof(float), hipMemcpyHostToDevice, st));
+    if (type)
+    {
+        HIP_TRY(hipMemcpyAsync(nb->d_type_in.p, type, (size_t)natoms * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(nb->d_q_in.p, q, (size_t)natoms * sizeof(float), hipMemcpyHostToDevice, st));
+    }
     const int all_pbc[3] = {1, 1, 1};
     if (nbx_search_grid_columns(nb->search, st, box, pbc_shift_dim ? pbc_shift_dim : all_pbc, natoms, d_x, atom_density))
     {
@@ -1215,6 +1225,12 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = nb->stream[0];
     const int  *d_ei = nullptr, *d_ea = nullptr;
+    if ((excl_index == nullptr) != (excl_a == nullptr)) { return nbx_fail("make_pairlist: exclusion index and atoms come together"); }
+    if (!excl_index && nb->excl_held && (int)nb->d_excl_index.n == nb->natoms_real + 1)
+    {
+        // the exclusions of the last call that passed them (same topology)
+        d_ei = nb->d_excl_index.p; d_ea = nb->d_excl_a.p;
+    }
     if (excl_index && excl_a)
     {
         const int n = nb->natoms_real, ne = excl_index[n];
@@ -1223,6 +1239,7 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
         HIP_TRY(hipMemcpyAsync(nb->d_excl_index.p, excl_index, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
         if (ne > 0) { HIP_TRY(hipMemcpyAsync(nb->d_excl_a.p, excl_a, (size_t)ne * sizeof(int), hipMemcpyHostToDevice, st)); }
         d_ei = nb->d_excl_index.p; d_ea = nb->d_excl_a.p;
+        nb->excl_held = true;
     }
     nbx_search_list_t L;
     if (nbx_search_make_pairlist(nb->search, st, rlist, min_ci_balanced, d_ei, d_ea, nb->xq.p, &L))
@@ -1241,6 +1258,13 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
     HIP_TRY(hipStreamSynchronize(st));
     pl.nsci = L.nsci; pl.ncj4 = L.ncj4; pl.nexcl = L.nexcl; pl.nci_tot = L.nci_tot; pl.rlist = rlist;
     pl.do_prune = true;
+    return 0;
+}
+
+int nbnxn_hip_forget_exclusions(nbnxn_hip_ptr_t nb)
+{
+    if (check_handle(nb)) { return 1; }
+    nb->excl_held = false;
     return 0;
 }
 

@@ -94,11 +94,17 @@ __device__ __forceinline__ int shift_index(int tx, int ty, int tz) { return 5 * 
 // gridding
 // ------------------------------------------------------------------------------------------
 
+__device__ __forceinline__ unsigned float_key_host_device(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // calc_column_indices: column of every atom (clamped: rounding at the upper edge), column
 // populations, and the sort key (column, z) whose stable sort reproduces "z ascending, ties by
 // atom index" of the host builder
-__global__ void k_columns(int n, const float *__restrict__ x, GridDims g, int *__restrict__ cxy_na,
-                          unsigned long long *__restrict__ key, int *__restrict__ val)
+__global__ void k_columns(int n, const float *__restrict__ x, GridDims g, unsigned long long *__restrict__ key,
+                          int *__restrict__ val)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) { return; }
@@ -109,20 +115,45 @@ __global__ void k_columns(int n, const float *__restrict__ x, GridDims g, int *_
     cx = min(max(cx, 0), g.ncx - 1);
     cy = min(max(cy, 0), g.ncy - 1);
     const int col = cx * g.ncy + cy;
-    atomicAdd(&cxy_na[col], 1);
-    unsigned u = __float_as_uint(pz);
-    u          = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    key[i]     = ((unsigned long long)(unsigned)col << 32) | u;
+    key[i]     = ((unsigned long long)(unsigned)col << 32) | float_key_host_device(pz);
     val[i]     = i;
 }
 
-// super-cells per column; entry ncxy is the zero that makes the exclusive scans yield the totals
-__global__ void k_column_cells(int ncxy, int *__restrict__ cxy_na, int *__restrict__ ncz)
+// column populations from the sorted keys (no atomics, no contention on crowded columns): the
+// atoms of column c are the keys in [c << 32, (c + 1) << 32).  Also the super-cells per column;
+// entry ncxy is the zero that makes the exclusive scans yield the totals.
+__device__ __forceinline__ int first_key_not_below(const unsigned long long *key, int n, unsigned long long v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (key[mid] < v) { lo = mid + 1; } else { hi = mid; }
+    }
+    return lo;
+}
+
+__global__ void k_column_cells(int ncxy, int n, const unsigned long long *__restrict__ sorted_key, int *__restrict__ cxy_na,
+                               int *__restrict__ ncz)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > ncxy) { return; }
     if (c == ncxy) { cxy_na[c] = 0; ncz[c] = 0; return; }
-    ncz[c] = (cxy_na[c] + NA_SC - 1) / NA_SC;
+    const int na = first_key_not_below(sorted_key, n, (unsigned long long)(c + 1) << 32)
+                 - first_key_not_below(sorted_key, n, (unsigned long long)c << 32);
+    cxy_na[c] = na;
+    ncz[c]    = (na + NA_SC - 1) / NA_SC;
+}
+
+// order-preserving map float -> unsigned (and back)
+__device__ __forceinline__ unsigned float_key(float v)
+{
+    const unsigned u = __float_as_uint(v + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
 struct SortItem {
@@ -167,7 +198,7 @@ k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, cons
              const int *__restrict__ atom_start, const int *__restrict__ sorted_atom, const float *__restrict__ x,
              const float *__restrict__ q, const int *__restrict__ type, int dummy_type, int *__restrict__ a_out,
              int *__restrict__ cell_out, float4 *__restrict__ xq, int *__restrict__ type_out, float *__restrict__ bb,
-             float *__restrict__ bbcz, int *__restrict__ nsubc, int *__restrict__ nsubc_tot)
+             float *__restrict__ bbcz, float *__restrict__ bbsc, int *__restrict__ nsubc, int *__restrict__ nsubc_tot)
 {
     const int sc   = blockIdx.x;
     const int lane = threadIdx.x;
@@ -225,12 +256,25 @@ k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, cons
             b[3 + d] = cl_has_atoms ? bhi[d] : 0.0f;
         }
     }
+    // box of the whole super-cell = union of its clusters' boxes (min / max are exact, so the order does not matter)
+#pragma unroll
+    for (int m = NA_C; m < NA_SC; m <<= 1)
+    {
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+        {
+            blo[d] = fminf(blo[d], __shfl_xor(blo[d], m));
+            bhi[d] = fmaxf(bhi[d], __shfl_xor(bhi[d], m));
+        }
+    }
     if (lane == 0)
     {
         const int ns  = min(NSUBC, (na_c + NA_C - 1) / NA_C);
         nsubc[sc]     = ns;
         bbcz[2 * sc]     = z_first;
         bbcz[2 * sc + 1] = z_last;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { bbsc[6 * sc + d] = blo[d]; bbsc[6 * sc + 3 + d] = bhi[d]; }
         atomicAdd(nsubc_tot, ns);
     }
 
@@ -250,6 +294,24 @@ k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, cons
         xq[gi]       = make_float4(-FAR_AWAY * (1 + NA_C * gx), -FAR_AWAY * (1 + NA_C * gy), -FAR_AWAY * (1 + NA_C * gz + (lane & 7)), 0.0f);
         type_out[gi] = dummy_type;
     }
+}
+
+// z-range of all atoms as order-preserving keys: the cells of a column are ordered in z, so the first and
+// the last cell of every column suffice.  One block; zrange was initialised to {max key, 0}.
+__global__ void k_zrange(int ncxy, const int *__restrict__ cxy_ind, const float *__restrict__ bbcz, unsigned *__restrict__ zrange)
+{
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for (int c = threadIdx.x; c < ncxy; c += blockDim.x)
+    {
+        const int c0 = cxy_ind[c], c1 = cxy_ind[c + 1];
+        if (c1 > c0)
+        {
+            kmin = min(kmin, float_key(bbcz[2 * c0]));
+            kmax = max(kmax, float_key(bbcz[2 * (c1 - 1) + 1]));
+        }
+    }
+    atomicMin(&zrange[0], kmin);
+    atomicMax(&zrange[1], kmax);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,7 +342,8 @@ __device__ __forceinline__ float bb_dist2(const float *a, const float *b)
 template <bool FILL>
 __global__ void __launch_bounds__(64)
 k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ nsubc, const float *__restrict__ bb,
-       const float *__restrict__ bbcz, const float4 *__restrict__ xq, int *__restrict__ ncj,
+       const float *__restrict__ bbcz, const float *__restrict__ bbsc, const unsigned *__restrict__ zrange,
+       const float4 *__restrict__ xq, int *__restrict__ ncj,
        const int *__restrict__ cj4_start, nbx_cj4_t *__restrict__ cj4, int *__restrict__ need_excl,
        unsigned *__restrict__ nci_tot)
 {
@@ -300,6 +363,29 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
     const float sh[3] = {tx * P.box[0], ty * P.box[1], tz * P.box[2]};
     const bool  central = (shift == NBX_CENTRAL);
 
+    // box of the whole i super-cell (unshifted union of its clusters' boxes, from the gridding pass), then shifted
+    float bS[6];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { bS[d] = bbsc[6 * sci + d] + sh[d]; bS[3 + d] = bbsc[6 * sci + 3 + d] + sh[d]; }
+    const GridDims &g = P.g;
+    int cxf = (int)floorf((bS[0] - P.rlist - g.c0[0]) * g.inv_sx);
+    int cxl = (int)floorf((bS[3] + P.rlist - g.c0[0]) * g.inv_sx);
+    int cyf = (int)floorf((bS[1] - P.rlist - g.c0[1]) * g.inv_sy);
+    int cyl = (int)floorf((bS[4] + P.rlist - g.c0[1]) * g.inv_sy);
+    cxf = max(cxf, 0); cxl = min(cxl, g.ncx - 1);
+    cyf = max(cyf, 0); cyl = min(cyl, g.ncy - 1);
+    // Many (super-cell, shift) combinations of a large box reach nothing: leave before staging anything.  In x and y
+    // that shows as an empty column window.  In z it is decided against the z-range of ALL atoms with a margin
+    // (0.1 % of rlist + 1e-3 nm) far above float rounding: when the shifted cell is further than that from every
+    // atom, the exact z-test below would reject every cell of every column as well, so the list is unchanged.
+    const float zmargin = P.rlist * 1.001f + 1e-3f;
+    const bool  none_in_z = (bS[5] + zmargin < key_float(zrange[0])) || (bS[2] - zmargin > key_float(zrange[1]));
+    if (cxf > cxl || cyf > cyl || none_in_z)
+    {
+        if (!FILL && lane == 0) { ncj[e] = 0; }
+        return;
+    }
+
     __shared__ float s_bbi[NSUBC][6];   // shifted i-cluster boxes
     __shared__ float s_xi[NA_SC][3];    // shifted i-atoms
     if (lane < NSUBC * 6)
@@ -314,58 +400,68 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
         s_xi[lane][2] = xa.z + sh[2];
     }
     __syncthreads();
-    // box of the whole i super-cell: unshifted union first, then shifted (the host's order of operations)
-    float bS[6];
-    {
-#pragma unroll
-        for (int w = 0; w < 6; w++) { bS[w] = w < 3 ? 1e30f : -1e30f; }
-        for (int ci = 0; ci < nsub_i; ci++)
-        {
-#pragma unroll
-            for (int d = 0; d < 3; d++)
-            {
-                bS[d]     = fminf(bS[d], bb[((size_t)sci * NSUBC + ci) * 6 + d]);
-                bS[3 + d] = fmaxf(bS[3 + d], bb[((size_t)sci * NSUBC + ci) * 6 + 3 + d]);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 3; d++) { bS[d] += sh[d]; bS[3 + d] += sh[d]; }
-    }
-    const GridDims &g = P.g;
-    int cxf = (int)floorf((bS[0] - P.rlist - g.c0[0]) * g.inv_sx);
-    int cxl = (int)floorf((bS[3] + P.rlist - g.c0[0]) * g.inv_sx);
-    int cyf = (int)floorf((bS[1] - P.rlist - g.c0[1]) * g.inv_sy);
-    int cyl = (int)floorf((bS[4] + P.rlist - g.c0[1]) * g.inv_sy);
-    cxf = max(cxf, 0); cxl = min(cxl, g.ncx - 1);
-    cyf = max(cyf, 0); cyl = min(cyl, g.ncy - 1);
 
     int       running = 0;   // j-clusters kept so far (wave-uniform)
     unsigned  npairs  = 0;   // cluster pairs of this lane's j-clusters
     const int base4   = FILL ? cj4_start[e] : 0;
 
-    for (int cx = cxf; cx <= cxl; cx++)
+    // Stage 1, one lane per column of the (cxf..cxl) x (cyf..cyl) window, in the host builder's column order:
+    // the column's distance in x and y and, since its cells are ordered in z, the run of cells the z-test
+    // (the host builder's expression) lets through -- found by bisection on that very expression from both ends.
+    // The lanes search their columns side by side, so the chain of dependent loads is one column long, not 25.
+    // Stage 2 then walks the columns in order, the 64 lanes on 8 cells x 8 clusters at a time.
+    const int ncoly = cyl - cyf + 1, ncol = (cxl - cxf + 1) * ncoly;
+    for (int colbase = 0; colbase < ncol; colbase += 64)
     {
-        float       d2x   = 0;
-        const float colx0 = g.c0[0] + cx * g.sx, colx1 = colx0 + g.sx;
-        if (colx0 > bS[3]) { d2x = sqr(colx0 - bS[3]); }
-        else if (colx1 < bS[0]) { d2x = sqr(bS[0] - colx1); }
-        if (d2x >= P.rl2) { continue; }
-        for (int cy = cyf; cy <= cyl; cy++)
+        int   my_lo = 0, my_hi = 0;
+        float my_d2xy = 0;
+        if (colbase + lane < ncol)
         {
+            const int   ic = colbase + lane;
+            const int   cx = cxf + ic / ncoly, cy = cyf + ic % ncoly;
+            float       d2x   = 0;
+            const float colx0 = g.c0[0] + cx * g.sx, colx1 = colx0 + g.sx;
+            if (colx0 > bS[3]) { d2x = sqr(colx0 - bS[3]); }
+            else if (colx1 < bS[0]) { d2x = sqr(bS[0] - colx1); }
             float       d2xy  = d2x;
             const float coly0 = g.c0[1] + cy * g.sy, coly1 = coly0 + g.sy;
             if (coly0 > bS[4]) { d2xy += sqr(coly0 - bS[4]); }
             else if (coly1 < bS[1]) { d2xy += sqr(bS[1] - coly1); }
-            if (d2xy >= P.rl2) { continue; }
-            int       c0 = cxy_ind[cx * g.ncy + cy];
-            const int c1 = cxy_ind[cx * g.ncy + cy + 1];
-            if (central) { c0 = max(c0, sci); }   // half list: j super-cells >= i (:5270-5283)
-            for (int cb = c0; cb < c1; cb += 8)
+            if (d2x < P.rl2 && d2xy < P.rl2)
+            {
+                int       c0 = cxy_ind[cx * g.ncy + cy];
+                const int c1 = cxy_ind[cx * g.ncy + cy + 1];
+                if (central) { c0 = max(c0, sci); }   // half list: j super-cells >= i (:5270-5283)
+                int a = c0, b = c1;
+                while (a < b)
+                {
+                    const int   mid = (a + b) >> 1;
+                    const float z1  = bbcz[2 * mid + 1];
+                    if (z1 < bS[2] && d2xy + sqr(bS[2] - z1) >= P.rl2) { a = mid + 1; } else { b = mid; }
+                }
+                my_lo = a;
+                b     = c1;
+                while (a < b)
+                {
+                    const int   mid = (a + b) >> 1;
+                    const float z0  = bbcz[2 * mid];
+                    if (z0 > bS[5] && d2xy + sqr(z0 - bS[5]) >= P.rl2) { b = mid; } else { a = mid + 1; }
+                }
+                my_hi   = a;
+                my_d2xy = d2xy;
+            }
+        }
+        const int nthis = min(64, ncol - colbase);
+        for (int k = 0; k < nthis; k++)
+        {
+            const int   z_lo = __shfl(my_lo, k), z_hi = __shfl(my_hi, k);
+            const float d2xy = __shfl(my_d2xy, k);
+            for (int cb = z_lo; cb < z_hi; cb += 8)
             {
                 const int scj = cb + (lane >> 3);
                 const int cjo = lane & 7;
                 unsigned  mb  = 0;
-                if (scj < c1 && cjo < nsubc[scj])
+                if (scj < z_hi && cjo < nsubc[scj])
                 {
                     float       d2 = d2xy;
                     const float z0 = bbcz[2 * scj], z1 = bbcz[2 * scj + 1];
@@ -388,14 +484,19 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
                         // a lone cluster pair beyond the box-only radius gets the atom check (:3073-3092)
                         if (np == 1 && d2_last >= P.rbb2)
                         {
+                            // all eight j-atoms are requested at once (a loop with an early exit would wait for
+                            // them one by one); "any pair in range" does not depend on the order of the tests
+                            float4 xj[NA_C];
+#pragma unroll
+                            for (int j = 0; j < NA_C; j++) { xj[j] = xq[(size_t)cj * NA_C + j]; }
                             bool in_range = false;
-                            for (int i = 0; i < NA_C && !in_range; i++)
+                            for (int i = 0; i < NA_C; i++)
                             {
                                 const float *xi = s_xi[ci_last * NA_C + i];
+#pragma unroll
                                 for (int j = 0; j < NA_C; j++)
                                 {
-                                    const float4 xj = xq[(size_t)cj * NA_C + j];
-                                    if (sqr(xi[0] - xj.x) + sqr(xi[1] - xj.y) + sqr(xi[2] - xj.z) < P.rl2) { in_range = true; break; }
+                                    in_range |= (sqr(xi[0] - xj[j].x) + sqr(xi[1] - xj[j].y) + sqr(xi[2] - xj[j].z) < P.rl2);
                                 }
                             }
                             if (!in_range) { mb = 0; }
@@ -613,7 +714,8 @@ struct nbx_search {
     // gridding
     Buf<int>                cxy_na, ncz, cxy_ind, atom_start, val_in, sorted_atom, a, cell, nsubc, counters;
     Buf<unsigned long long> key_in, key_out;
-    Buf<float>              bb, bbcz;
+    Buf<float>              bb, bbcz, bbsc;
+    Buf<unsigned>           zrange;
     // list
     Buf<int>        ncj, ncj4_e, cj4_start, need_excl, excl_rank, nparts, part_start;
     Buf<nbx_cj4_t>  cj4;
@@ -630,7 +732,7 @@ void nbx_search_destroy(nbx_search *s)
     if (!s) { return; }
     s->cxy_na.release(); s->ncz.release(); s->cxy_ind.release(); s->atom_start.release(); s->val_in.release();
     s->sorted_atom.release(); s->a.release(); s->cell.release(); s->nsubc.release(); s->counters.release();
-    s->key_in.release(); s->key_out.release(); s->bb.release(); s->bbcz.release();
+    s->key_in.release(); s->key_out.release(); s->bb.release(); s->bbcz.release(); s->bbsc.release(); s->zrange.release();
     s->ncj.release(); s->ncj4_e.release(); s->cj4_start.release(); s->need_excl.release(); s->excl_rank.release();
     s->nparts.release(); s->part_start.release(); s->cj4.release(); s->excl.release(); s->sci_a.release(); s->sci_b.release();
     s->skey_in.release(); s->skey_out.release();
@@ -673,16 +775,16 @@ int nbx_search_grid_columns(nbx_search *s, hipStream_t st, const float box[3], c
     if (s->cxy_na.reserve(ncxy + 1) || s->ncz.reserve(ncxy + 1) || s->cxy_ind.reserve(ncxy + 1) || s->atom_start.reserve(ncxy + 1)
         || s->key_in.reserve(n) || s->key_out.reserve(n) || s->val_in.reserve(n) || s->sorted_atom.reserve(n)
         || s->counters.reserve(8)) { return 1; }
-    S_TRY(hipMemsetAsync(s->cxy_na.p, 0, (ncxy + 1) * sizeof(int), st));
     S_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(int), st));
-    hipLaunchKernelGGL(k_columns, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, d_x, g, s->cxy_na.p, s->key_in.p, s->val_in.p);
-    hipLaunchKernelGGL(k_column_cells, dim3(blocks_for(ncxy + 1, 256)), dim3(256), 0, st, ncxy, s->cxy_na.p, s->ncz.p);
+    hipLaunchKernelGGL(k_columns, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, d_x, g, s->key_in.p, s->val_in.p);
     S_TRY(hipGetLastError());
-    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncz.p, s->cxy_ind.p, ncxy + 1, st));
-    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->cxy_na.p, s->atom_start.p, ncxy + 1, st));
     int col_bits = 1;
     while ((1 << col_bits) < ncxy) { col_bits++; }
     S_TRY(nbx_prim_sort_u64_int(s->tmp, s->key_in.p, s->key_out.p, s->val_in.p, s->sorted_atom.p, n, 32 + col_bits, st));
+    hipLaunchKernelGGL(k_column_cells, dim3(blocks_for(ncxy + 1, 256)), dim3(256), 0, st, ncxy, n, s->key_out.p, s->cxy_na.p, s->ncz.p);
+    S_TRY(hipGetLastError());
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncz.p, s->cxy_ind.p, ncxy + 1, st));
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->cxy_na.p, s->atom_start.p, ncxy + 1, st));
     int nc = 0;
     S_TRY(hipMemcpyAsync(&nc, s->cxy_ind.p + ncxy, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
@@ -699,10 +801,15 @@ int nbx_search_grid_fill(nbx_search *s, hipStream_t st, const float *d_x, const 
     if (!s || !s->have_columns) { return sfail("grid_fill before grid_columns"); }
     const size_t npad = (size_t)s->nc * NA_SC;
     if (s->a.reserve(npad) || s->cell.reserve(s->natoms) || s->nsubc.reserve(s->nc) || s->bb.reserve((size_t)s->nc * NSUBC * 6)
-        || s->bbcz.reserve((size_t)s->nc * 2)) { return 1; }
+        || s->bbcz.reserve((size_t)s->nc * 2) || s->bbsc.reserve((size_t)s->nc * 6) || s->zrange.reserve(2)) { return 1; }
+    {
+        static const unsigned init[2] = {0xffffffffu, 0u};
+        S_TRY(hipMemcpyAsync(s->zrange.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    }
     hipLaunchKernelGGL(k_supercells, dim3(s->nc), dim3(64), 0, st, s->nc, s->ncxy, s->g, s->cxy_ind.p, s->cxy_na.p, s->atom_start.p,
                        s->sorted_atom.p, d_x, d_q, d_type, ntype_with_dummy - 1, s->a.p, s->cell.p, d_xq, d_type_out, s->bb.p,
-                       s->bbcz.p, s->nsubc.p, s->counters.p);
+                       s->bbcz.p, s->bbsc.p, s->nsubc.p, s->counters.p);
+    hipLaunchKernelGGL(k_zrange, dim3(1), dim3(256), 0, st, s->ncxy, s->cxy_ind.p, s->bbcz.p, s->zrange.p);
     S_TRY(hipGetLastError());
     s->have_grid = true;
     s->nsubc_tot = -1;   // read back when the list needs it
@@ -784,7 +891,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min
     if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)
         || s->part_start.reserve(nent + 1)) { return 1; }
     S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));
-    hipLaunchKernelGGL((k_list<false>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, d_xq, s->ncj.p,
+    hipLaunchKernelGGL((k_list<false>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
                        (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)nullptr);
     hipLaunchKernelGGL(k_groups_of, dim3(blocks_for(nent + 1, 256)), dim3(256), 0, st, nent, s->ncj.p, s->ncj4_e.p);
     S_TRY(hipGetLastError());
@@ -800,7 +907,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min
     if (s->cj4.reserve((size_t)ncj4 + 1) || s->need_excl.reserve(2 * (size_t)ncj4 + 1) || s->excl_rank.reserve(2 * (size_t)ncj4 + 1)) { return 1; }
     S_TRY(hipMemsetAsync(s->cj4.p, 0, ((size_t)ncj4 + 1) * sizeof(nbx_cj4_t), st));
     S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
-    hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, d_xq, s->ncj.p,
+    hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
                        s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1));
     hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);

@@ -93,6 +93,7 @@ def load():
     lib.nbnxn_hip_download_coulomb_tab.argtypes = [vp, vp, ci, C.POINTER(ci), C.POINTER(cf)]
     lib.nbnxn_hip_put_on_grid.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, cf]
     lib.nbnxn_hip_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci]
+    lib.nbnxn_hip_forget_exclusions.argtypes = [vp]
     lib.nbnxn_hip_download_grid.argtypes = [vp] + [vp] * 8
     lib.nbnxn_hip_download_pairlist.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.nbnxn_hip_set_atom_order.argtypes = [vp, ci, vp, vp]
@@ -161,15 +162,16 @@ class NbnxnHip:
         """nbnxn_put_on_grid + nbnxn_atomdata_set + init_atomdata + copy_x on the device.  x: numpy
         [n,3] or an object with __cuda_array_interface__ (device array).  Returns the padded atom count."""
         box = np.ascontiguousarray(box, dtype=np.float32)
-        type_ = np.ascontiguousarray(type_, dtype=np.int32)
-        q = np.ascontiguousarray(q, dtype=np.float32)
+        if type_ is not None:
+            type_ = np.ascontiguousarray(type_, dtype=np.int32)
+            q = np.ascontiguousarray(q, dtype=np.float32)
         pbc = None if pbc_shift_dim is None else np.ascontiguousarray(pbc_shift_dim, dtype=np.int32)
         if hasattr(x, "__cuda_array_interface__"):
             xp, on_dev, n = C.c_void_p(x.__cuda_array_interface__["data"][0]), 1, x.__cuda_array_interface__["shape"][0]
         else:
             x = np.ascontiguousarray(x, dtype=np.float32)
             xp, on_dev, n = abi.ptr(x), 0, len(x)
-        assert len(type_) == n and len(q) == n
+        assert type_ is None or (len(type_) == n and len(q) == n)
         self._chk(self.lib.nbnxn_hip_put_on_grid(self.h, abi.ptr(box), abi.ptr(pbc), n, xp, on_dev, abi.ptr(type_), abi.ptr(q),
                                                  atom_density))
         dims = np.zeros(4, dtype=np.int32)
@@ -183,6 +185,9 @@ class NbnxnHip:
             excl_index = np.ascontiguousarray(excl_index, dtype=np.int32)
             excl_a = np.ascontiguousarray(excl_a, dtype=np.int32)
         self._chk(self.lib.nbnxn_hip_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a), min_ci_balanced))
+
+    def forget_exclusions(self):
+        self._chk(self.lib.nbnxn_hip_forget_exclusions(self.h))
 
     def download_grid(self):
         dims = np.zeros(4, dtype=np.int32)

@@ -421,16 +421,20 @@ int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, in
  * coordinates+charges (with fillers), types (dummy type = ntype - 1 of init_const), atom-order
  * arrays (as nbnxn_hip_set_atom_order would) and shift vectors.  x [natoms][3] may be a host or a
  * device array; type and q are host arrays in caller order; pbc_shift_dim NULL = periodic in
- * x, y and z; atom_density <= 0 = natoms / volume.  Invalidates the lists.  Call after init_const. */
+ * x, y and z; atom_density <= 0 = natoms / volume.  type = q = NULL reuses the arrays of the last
+ * call (the topology is constant between searches; natoms must agree).  Invalidates the lists.
+ * Call after init_const. */
 int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
                           int x_on_device, const int *type, const float *q, float atom_density);
 
 /* Builds the local list for the atoms gridded by nbnxn_hip_put_on_grid and installs it as
  * nbnxn_hip_init_pairlist would (its first kernel prunes it).  excl_index [natoms+1] / excl_a:
- * topology exclusions in caller atom numbering (t_blocka index / a), NULL for none;
+ * topology exclusions in caller atom numbering (t_blocka index / a); NULL = those of the last call
+ * that passed them (none if there was no such call: use nbnxn_hip_forget_exclusions to drop them);
  * min_ci_balanced as for nbnxn_make_pairlist (nbnxn_hip_min_ci_balanced()).  iloc must be
  * NBX_LOCAL: halo zones stay with the host-side builder. */
 int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced);
+int nbnxn_hip_forget_exclusions(nbnxn_hip_ptr_t nb);
 
 /* Verification aids: the device grid (dims = {ncx, ncy, number of super-cells, padded atoms};
  * a [padded], cell [natoms], bb [clusters][6] = lo xyz, hi xyz, bbcz [super-cells][2],

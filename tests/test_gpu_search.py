@@ -122,6 +122,7 @@ def test_device_search_edge_cases(nb):
         h.copy_x_to_xq(x, xq)
         pl = h.make_pairlist(abi.LOCAL, ip.rlist, xq, None, None, 0)
         nb.init_const(ip, 3, nbfp)
+        nb.forget_exclusions()                      # an earlier test's topology must not leak in
         assert nb.put_on_grid(box, x, typ, q, pbc_shift_dim=pbc) == len(xq)
         nb.make_pairlist(ip.rlist, None, None, 0)
         grid = nb.download_grid()
@@ -141,8 +142,8 @@ def test_device_search_follows_moving_atoms(nb):
     rng = np.random.default_rng(9)
     x2 = np.mod(s.x + rng.normal(0, 0.05, s.x.shape), s.box).astype(np.float32)
     xd = torch.from_numpy(x2).cuda()
-    nb.put_on_grid(s.box, xd, s.type, s.q)
-    nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0)
+    nb.put_on_grid(s.box, xd, None, None)           # topology held from the first search
+    nb.make_pairlist(ip.rlist, None, None, 0)
     import dataclasses
     s2 = dataclasses.replace(s, x=x2)
     p = g.workload.prepare(s2, ip, 0)
@@ -161,6 +162,8 @@ def test_device_search_refusals(nb):
         nb.make_pairlist(1.0, s.excl_index, s.excl_a, 0)                             # box 1.86 < 2 rlist
     with pytest.raises(RuntimeError):
         nb.put_on_grid(s.box, s.x, s.type + 7, s.q)                                  # types outside the LJ table
+    with pytest.raises(RuntimeError):
+        nb.put_on_grid(s.box, s.x[:100], None, None)                                 # held topology is for another atom count
     # a host-side init_atomdata invalidates the device grid
     p = g.workload.prepare(s, ip, 0)
     g.workload.upload(nb, p, ip)

@@ -1,7 +1,8 @@
 """Kernel time of every flavour axis on the 97k-atom water box (event timing of the module,
 resident coordinates): electrostatics x LJ treatment, F and V+F.  usage: python tools/flavour_bench.py"""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gromacs_cosmo_amd as g
 from gromacs_cosmo_amd import abi
