@@ -165,3 +165,12 @@ def ptr(a):
     if a is None:
         return None
     return a.ctypes.data_as(C.c_void_p)
+
+
+class GpuDevInfo(C.Structure):
+    """nbx_gpu_dev_info_t (include/nbnxn_hip.h): the plain-type stand-in for cuda_dev_info_t."""
+    _fields_ = [("id", C.c_int), ("stat", C.c_int), ("name", C.c_char * 256), ("arch", C.c_char * 64),
+                ("compute_units", C.c_int), ("clock_mhz", C.c_int), ("total_mem", C.c_size_t)]
+
+
+GPU_COMPATIBLE, GPU_NONEXISTENT, GPU_INCOMPATIBLE, GPU_INSANE = 0, 1, 2, 3

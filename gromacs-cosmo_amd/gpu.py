@@ -53,6 +53,14 @@ def load():
     lib.nbnxn_hip_set_abort_on_error.argtypes = [ci]
     lib.nbnxn_hip_detect_gpus.argtypes = [C.POINTER(ci), C.c_char_p, ci]
     lib.nbnxn_hip_get_gpu_device_info_string.argtypes = [C.c_char_p, ci, ci]
+    lib.nbnxn_hip_sizeof_dev_info.restype = C.c_size_t
+    lib.nbnxn_hip_detect_gpus_info.argtypes = [C.POINTER(abi.GpuDevInfo), ci, C.POINTER(ci), C.POINTER(ci), C.c_char_p, ci]
+    lib.nbnxn_hip_pick_compatible_gpus.argtypes = [C.POINTER(abi.GpuDevInfo), ci, C.POINTER(ci), ci, C.POINTER(ci)]
+    lib.nbnxn_hip_check_selected_gpus.argtypes = [C.POINTER(ci), C.POINTER(abi.GpuDevInfo), ci, C.POINTER(ci), ci]
+    lib.nbnxn_hip_get_gpu_device_id.argtypes = [C.POINTER(abi.GpuDevInfo), ci, C.POINTER(ci), ci, ci]
+    lib.nbnxn_hip_do_quick_memtest.argtypes = [ci]
+    lib.nbnxn_hip_do_full_memtest.argtypes = [ci]
+    lib.nbnxn_hip_do_timed_memtest.argtypes = [ci, ci]
     lib.nbnxn_hip_pmalloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.nbnxn_hip_pfree.argtypes = [vp]
     lib.nbnxn_hip_init.argtypes = [vp, C.POINTER(vp), ci, ci]
@@ -118,6 +126,19 @@ def detect_gpus():
     if rc != 0:
         raise HipError("no usable GPU: " + buf.value.decode())
     return n.value
+
+
+def detect_gpus_info():
+    """detect_cuda_gpus with the per-device checks: list of abi.GpuDevInfo, number of compatible devices."""
+    lib = load()
+    n, nc = C.c_int(0), C.c_int(0)
+    buf = C.create_string_buffer(256)
+    if lib.nbnxn_hip_detect_gpus_info(None, 0, C.byref(n), C.byref(nc), buf, 256) != 0:
+        raise HipError("GPU detection failed: " + buf.value.decode())
+    info = (abi.GpuDevInfo * max(n.value, 1))()
+    if lib.nbnxn_hip_detect_gpus_info(info, n.value, C.byref(n), C.byref(nc), buf, 256) != 0:
+        raise HipError("GPU detection failed: " + buf.value.decode())
+    return info, n.value, nc.value
 
 
 class NbnxnHip:

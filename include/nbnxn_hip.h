@@ -262,7 +262,7 @@ void        nbnxn_hip_set_abort_on_error(int abort_on_error);
 const char *nbnxn_hip_last_error(void);
 
 /* ------------------------------------------------------------------------------------
- * Device selection; replaces detect_cuda_gpus / init_gpu / free_gpu /
+ * Device selection; replaces detect_cuda_gpus / init_gpu / free_gpu / get_current_gpu_device_id /
  * get_gpu_device_info_string (legacyheaders/gpu_utils.h:72-104).
  * ---------------------------------------------------------------------------------- */
 int nbnxn_hip_detect_gpus(int *ngpu, char *err_str, int err_len);
@@ -270,6 +270,40 @@ int nbnxn_hip_init_gpu(int device_id, char *result_str, int result_len);
 int nbnxn_hip_free_gpu(char *result_str, int result_len);
 int nbnxn_hip_get_current_gpu_device_id(void);
 int nbnxn_hip_get_gpu_device_info_string(char *s, int len, int device_id);
+
+/* The rest of gpu_utils.h behind plain types.  nbx_gpu_dev_info_t stands for cuda_dev_info_t
+ * (gmxlib/cuda_tools/cudautils.cuh:116-122; it embeds cudaDeviceProp there), an array of them for
+ * gmx_gpu_info_t.cuda_dev, a list of indices into it for gmx_gpu_opt_t.cuda_dev_use; both arrays
+ * belong to the caller, so free_gpu_info (gpu_utils.h:84) has nothing to free here. */
+enum { NBX_GPU_COMPATIBLE = 0, NBX_GPU_NONEXISTENT = 1, NBX_GPU_INCOMPATIBLE = 2, NBX_GPU_INSANE = 3 };   /* egpu*, types/hw_info.h:57 */
+typedef struct {
+    int    id;              /* device id */
+    int    stat;            /* NBX_GPU_*: result of the sanity check (a dummy kernel) and of the architecture check */
+    char   name[256];
+    char   arch[64];        /* gcnArchName; compatible = gfx950, the only code objects this library carries */
+    int    compute_units;
+    int    clock_mhz;
+    size_t total_mem;
+} nbx_gpu_dev_info_t;
+/* sizeof_cuda_dev_info (gpu_utils.h:107): for broadcasting the array between ranks */
+size_t nbnxn_hip_sizeof_dev_info(void);
+/* detect_cuda_gpus (gpu_utils.h:72) with the per-device checks of is_gmx_supported_gpu_id: fills
+ * up to info_alloc entries, counts all devices and the compatible ones; non-zero on an API failure */
+int nbnxn_hip_detect_gpus_info(nbx_gpu_dev_info_t *info, int info_alloc, int *ndev, int *ndev_compatible, char *err_str, int err_len);
+/* pick_compatible_gpus (gpu_utils.h:75): indices of the compatible devices, in increasing order */
+int nbnxn_hip_pick_compatible_gpus(const nbx_gpu_dev_info_t *info, int ndev, int *dev_use, int dev_use_alloc, int *ndev_use);
+/* check_selected_cuda_gpus (gpu_utils.h:79): checkres[i] = NBX_GPU_* of dev_use[i]; returns 1 iff all are compatible */
+int nbnxn_hip_check_selected_gpus(int *checkres, const nbx_gpu_dev_info_t *info, int ndev, const int *dev_use, int ndev_use);
+/* get_gpu_device_id (gpu_utils.h:99): device id of the index-th selected device, -1 if out of range */
+int nbnxn_hip_get_gpu_device_id(const nbx_gpu_dev_info_t *info, int ndev, const int *dev_use, int ndev_use, int index);
+/* do_quick_memtest / do_full_memtest / do_timed_memtest (gpu_utils.h:63-69): device memory tests
+ * (moving inversions, modulo-20, address-dependent pseudo-random words; the reference links the
+ * memtestG80 library for the same families).  dev_id -1 = the device in use.  Quick: 250 MiB, one
+ * pass; full: 90 % of the free memory, two passes; timed: the same, repeated for time_limit
+ * seconds.  Return 0 = no error found, > 0 = mismatching words, -1 = the test could not run. */
+int nbnxn_hip_do_quick_memtest(int dev_id);
+int nbnxn_hip_do_full_memtest(int dev_id);
+int nbnxn_hip_do_timed_memtest(int dev_id, int time_limit);
 
 /* pinned host memory; replaces pmalloc / pfree (legacyheaders/pmalloc_cuda.h:57,63),
  * the nbnxn_alloc_t / nbnxn_free_t hooks handed to nbnxn_init_pairlist_set and

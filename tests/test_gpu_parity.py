@@ -564,3 +564,33 @@ def test_tabulated_ewald_flavour(nb):
     _upload(nb, p, ana)
     assert nb.is_kernel_ewald_analytical()
     _check_against(*nb.compute(p.xq, abi.FORCE_VIRIAL), p, ana, o_ana)
+
+
+def test_device_selection_and_memory_test(nb):
+    """the gpu_utils.h surface (detect / pick / check / device id / memtest) on the box's one MI355X"""
+    lib = nb.lib
+    info, ndev, ncompat = g.gpu.detect_gpus_info()
+    assert ndev >= 1 and ncompat >= 1 and lib.nbnxn_hip_sizeof_dev_info() == C.sizeof(abi.GpuDevInfo)
+    assert info[0].id == 0 and info[0].stat == abi.GPU_COMPATIBLE and info[0].arch.decode().startswith("gfx950")
+    assert info[0].compute_units == 256 and info[0].total_mem > 200 * 2 ** 30
+    use = (C.c_int * ndev)()
+    nuse = C.c_int(0)
+    assert lib.nbnxn_hip_pick_compatible_gpus(info, ndev, use, ndev, C.byref(nuse)) == 0
+    assert nuse.value == ncompat and use[0] == 0
+    assert lib.nbnxn_hip_get_gpu_device_id(info, ndev, use, nuse.value, 0) == 0
+    assert lib.nbnxn_hip_get_gpu_device_id(info, ndev, use, nuse.value, nuse.value) == -1
+    # a selection with a device that does not exist
+    sel = (C.c_int * 2)(0, ndev + 3)
+    res = (C.c_int * 2)()
+    assert lib.nbnxn_hip_check_selected_gpus(res, info, ndev, sel, 2) == 0
+    assert list(res) == [abi.GPU_COMPATIBLE, abi.GPU_NONEXISTENT]
+    assert lib.nbnxn_hip_check_selected_gpus(res, info, ndev, sel, 1) == 1
+    # detection must leave the current device alone, and the module still works afterwards
+    assert lib.nbnxn_hip_get_current_gpu_device_id() == 0
+    assert lib.nbnxn_hip_do_quick_memtest(-1) == 0
+    assert lib.nbnxn_hip_do_timed_memtest(0, 1) == 0
+    assert lib.nbnxn_hip_do_quick_memtest(ndev + 3) == -1
+    p, ip, d = load_small("spc216_rf09")
+    _upload(nb, p, ip)
+    f, _ = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert relrms(f, d["ref_f"]) < FORCE_RTOL
