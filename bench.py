@@ -49,6 +49,37 @@ def oracle_check(prep, ip, f_gpu, e_gpu):
             "pairs_in_cutoff_non_filler": int(o["counts"][2])}
 
 
+def verlet_loop_leg(g, abi, system, ip, flags, nstlist=10, nsteps=100):
+    """Secondary figure, outside the timed region of `value`: the whole device-resident step of
+    gromacs-cosmo_amd/verlet.py (search on the device every nstlist steps, x gather, kernel, f scatter
+    into a caller-order device array), atoms at rest, list radius = cut-off as in the headline config."""
+    import time
+    import torch
+    nb = g.gpu.NbnxnHip(0)
+    nb.set_timing(False)
+    nb.set_clear_in_kernel(True)
+    loop = g.verlet.VerletLoop(nb, system, ip, nstlist=nstlist)
+    xd = torch.from_numpy(system.x).cuda()
+    fd = torch.zeros_like(xd)
+    for _ in range(nstlist + 2):
+        loop.force(xd, fd, flags & ~abi.FORCE_VIRIAL)        # warm-up incl. one search
+    loop.step = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        loop.force(xd, fd, flags & ~abi.FORCE_VIRIAL)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / nsteps
+    t0 = time.perf_counter()
+    for _ in range(5):
+        loop.search(xd)
+    torch.cuda.synchronize()
+    search_ms = (time.perf_counter() - t0) * 1e3 / 5
+    nb.close()
+    return {"ms_per_step": ms, "nstlist": nstlist, "steps": nsteps, "search_ms": search_ms,
+            "note": "forces only; device search + x gather + kernel + f scatter per step, caller-order x and f resident in HBM"}
+
+
 def cpu_baseline(prep, ip, seconds=12.0):
     """The reference's plain-C nbnxn_kernel_ref (oracle/_ref, compiled from the reference tree)
     on the host cores, same atoms and pairs (as a 4x4 list); falls back to the repo's scalar
@@ -242,6 +273,7 @@ def main():
             chk = oracle_check(prep, ip, f0, e0)
             out["parity"] = chk
             out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
+            out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -3,4 +3,4 @@
 Only what the hot path needs: the HIP kernels and C ABI (csrc/, include/), the host-side
 list producers, and Python mirrors used by tests, bench.py and the multi-GPU driver.
 """
-from . import abi, gpu, host, system, workload  # noqa: F401
+from . import abi, gpu, host, system, verlet, workload  # noqa: F401

@@ -169,3 +169,39 @@ def test_device_search_refusals(nb):
     g.workload.upload(nb, p, ip)
     with pytest.raises(RuntimeError):
         nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0)
+
+
+@pytest.mark.parametrize("kind", ["water", "chains"])
+def test_verlet_loop_with_moving_atoms(nb, kind):
+    """The callers either side of the kernel in the reference's order (gromacs-cosmo_amd/verlet.py = the
+    device-resident do_force_cutsVERLET): search every 5 steps with a 0.1 nm buffer, atoms drifting in between
+    (some out of the box), the list reused and pruned once.  Every step's forces, in caller order, against the
+    oracle on a FRESH host-built list for that step's positions."""
+    import dataclasses
+    import torch
+    if kind == "water":
+        s, base = g.system.water_box(2, 2, 2, model="spce"), g.system.ewald(0.9)
+    else:
+        s, base = g.system.lj_chain_mixture(3000), g.system.reaction_field(0.9)
+    ip = dataclasses.replace(base, rlist=1.0)
+    ip_exact = base                                        # oracle side: list radius = cut-off
+    loop = g.verlet.VerletLoop(nb, s, ip, nstlist=5, min_ci_balanced=200)
+    rng = np.random.default_rng(3)
+    x = s.x.copy()
+    vel = rng.normal(0, 0.004, x.shape).astype(np.float32)   # <= ~0.015 nm per step, 4 steps between searches
+    for step in range(11):
+        if step % 5 == 0:
+            x = np.mod(x, s.box).astype(np.float32)         # put_atoms_in_box on search steps
+        xd = torch.from_numpy(x).cuda()
+        fd = torch.zeros_like(xd)
+        e = loop.force(xd, fd, abi.FORCE_VIRIAL)
+        torch.cuda.synchronize()
+        f = fd.cpu().numpy()
+        p = g.workload.prepare(dataclasses.replace(s, x=np.mod(x, s.box).astype(np.float32)), ip_exact, 0)
+        o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip_exact)
+        fo = np.zeros((s.natoms, 3), dtype=np.float32)
+        p.host.add_f(np.asarray(o["f"], dtype=np.float32), fo)
+        assert relrms(f, fo) < FORCE_RTOL, step
+        assert abs(e[0] - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"]) and abs(e[1] - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"]), step
+        x = x + vel
+    assert loop.nsearch == 3
