@@ -82,6 +82,10 @@ struct PList {
     int                nsci = 0, ncj4 = 0, nexcl = 0, nci_tot = 0;
     float              rlist = 0;
     bool               do_prune = false;
+    // dynamic pruning (nbnxn_hip_launch_kernel_pruneonly): outer masks beside the list, rolling position
+    DevBuf<unsigned>   imask_outer;
+    bool               have_outer = false;
+    int                rolling_part = 0, rolling_nparts = 0;
 };
 
 } // namespace
@@ -377,7 +381,7 @@ int init_pairlist_impl(nbnxn_hip *nb, int iloc, float rlist, int nsci, const nbx
         HIP_TRY(hipStreamSynchronize(st));   // the host arrays may be reused by the caller
     }
     pl.nsci = nsci; pl.ncj4 = ncj4; pl.nexcl = nexcl; pl.nci_tot = nci_tot; pl.rlist = rlist;
-    pl.do_prune = true;   // a fresh list gets pruned by its first kernel (nbnxn_cuda_data_mgmt.cu:792-794)
+    pl.do_prune = true; pl.have_outer = false;   // a fresh list gets pruned by its first kernel (nbnxn_cuda_data_mgmt.cu:792-794)
     return 0;
 }
 
@@ -882,7 +886,7 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     dev_free(nb->xq); (void)hipFree(nb->fbase); nb->fbase = nullptr; nb->f = DevBuf<float>(); nb->out = nullptr; dev_free(nb->type); dev_free(nb->nbfp);
     for (int l = 0; l < 2; l++)
     {
-        dev_free(nb->plist[l].sci); dev_free(nb->plist[l].cj4); dev_free(nb->plist[l].excl);
+        dev_free(nb->plist[l].sci); dev_free(nb->plist[l].cj4); dev_free(nb->plist[l].excl); dev_free(nb->plist[l].imask_outer);
         (void)hipEventDestroy(nb->k_start[l]);   (void)hipEventDestroy(nb->k_stop[l]);
         (void)hipEventDestroy(nb->h2d_start[l]); (void)hipEventDestroy(nb->h2d_stop[l]);
         (void)hipEventDestroy(nb->d2h_start[l]); (void)hipEventDestroy(nb->d2h_stop[l]);
@@ -1257,7 +1261,7 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
     }
     HIP_TRY(hipStreamSynchronize(st));
     pl.nsci = L.nsci; pl.ncj4 = L.ncj4; pl.nexcl = L.nexcl; pl.nci_tot = L.nci_tot; pl.rlist = rlist;
-    pl.do_prune = true;
+    pl.do_prune = true; pl.have_outer = false;
     return 0;
 }
 
@@ -1356,6 +1360,37 @@ int nbnxn_hip_add_f(nbnxn_hip_ptr_t nb, float *f, int f_on_device, int a0, int n
     HIP_TRY(hipStreamSynchronize(st));
     float *o = f + (size_t)a0 * 3;
     for (size_t i = 0; i < (size_t)n * 3; i++) { o[i] += nb->h_fa[i]; }
+    return 0;
+}
+
+int nbnxn_hip_launch_kernel_pruneonly(nbnxn_hip_ptr_t nb, int iloc, float rlist_inner, int num_parts)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    PList &pl = nb->plist[iloc];
+    if (pl.nsci == 0) { return 0; }
+    if (!nb->shift_vec_uploaded) { return nbx_fail("pruneonly before upload_shiftvec"); }
+    if (!(rlist_inner > 0) || rlist_inner > pl.rlist) { return nbx_fail("inner list radius %g must be in (0, rlist = %g]", rlist_inner, pl.rlist); }
+    if (num_parts < 1 || num_parts > pl.nsci) { return nbx_fail("cannot prune in %d parts a list of %d entries", num_parts, pl.nsci); }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = nb->stream[iloc];
+    if (!pl.have_outer)
+    {
+        // first pass over a new list: the outer masks (what the first force kernel would have left, had it
+        // pruned) are set aside, the list itself gets the inner ones; all of it, whatever num_parts says
+        if (dev_reserve(pl.imask_outer, pl.ncj4)) { return 1; }
+        HIP_TRY(nbx_launch_prune(nb->xq.p, nb->shift_vec, pl.sci.p, pl.cj4.p, pl.imask_outer.p, 0, pl.nsci, true, pl.rlist, rlist_inner, st));
+        pl.have_outer     = true;
+        pl.do_prune       = false;
+        pl.rolling_part   = 0;
+        pl.rolling_nparts = num_parts;
+        return 0;
+    }
+    if (pl.do_prune) { return nbx_fail("the list was replaced without its outer masks being reset"); }
+    if (num_parts != pl.rolling_nparts) { pl.rolling_part = 0; pl.rolling_nparts = num_parts; }
+    const int part  = pl.rolling_part;
+    const int begin = (int)((long long)pl.nsci * part / num_parts), end = (int)((long long)pl.nsci * (part + 1) / num_parts);
+    HIP_TRY(nbx_launch_prune(nb->xq.p, nb->shift_vec, pl.sci.p, pl.cj4.p, pl.imask_outer.p, begin, end - begin, false, pl.rlist, rlist_inner, st));
+    pl.rolling_part = (part + 1) % num_parts;
     return 0;
 }
 

@@ -85,6 +85,11 @@ hipError_t nbx_launch_nonbonded_rf(const nbx_kernel_args_t &a, int nsci, bool en
 hipError_t nbx_launch_nonbonded_ewald_ana(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream);
 hipError_t nbx_launch_nonbonded_ewald_tab(const nbx_kernel_args_t &a, int nsci, bool ener, bool prune, bool vdw_cutoff, int vdw_mod, hipStream_t stream);
 
+// nbnxn_prune.hip: prune-only pass over sci[sci_begin, sci_begin + nsci); fresh = the list has not been
+// pruned yet (outer masks are produced from the list's own masks with rlist_outer)
+hipError_t nbx_launch_prune(const float4 *xq, const float *shift_vec, const nbx_sci_t *sci, nbx_cj4_t *cj4, unsigned *imask_outer,
+                            int sci_begin, int nsci, bool fresh, float rlist_outer, float rlist_inner, hipStream_t stream);
+
 // nbnxn_atomdata.hip
 hipError_t nbx_launch_gather_x(const int *a, const float *x, float4 *xq, int begin, int n, hipStream_t stream);
 hipError_t nbx_launch_scatter_f(const int *cell, const float *fnb, float *f, int a0, int n, bool add, hipStream_t stream);

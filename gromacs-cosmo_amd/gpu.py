@@ -99,6 +99,7 @@ def load():
     lib.nbnxn_hip_set_vdw_modifier_flat.argtypes = [vp, ci] + [cf] * 8
     lib.nbnxn_hip_set_ljpme_flat.argtypes = [vp, ci, cf, cf, vp]
     lib.nbnxn_hip_download_coulomb_tab.argtypes = [vp, vp, ci, C.POINTER(ci), C.POINTER(cf)]
+    lib.nbnxn_hip_launch_kernel_pruneonly.argtypes = [vp, ci, cf, ci]
     lib.nbnxn_hip_put_on_grid.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, cf]
     lib.nbnxn_hip_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci]
     lib.nbnxn_hip_forget_exclusions.argtypes = [vp]
@@ -177,6 +178,10 @@ class NbnxnHip:
             comb = nbfp_comb(nbfp, ntype, ip.ljpme_comb_rule)
             self._chk(self.lib.nbnxn_hip_set_ljpme_flat(self.h, ip.ljpme_comb_rule, ip.ewaldcoeff_lj, ip.sh_lj_ewald,
                                                         abi.ptr(comb)))
+
+    def prune_only(self, rlist_inner, num_parts=1, iloc=abi.LOCAL):
+        """dynamic pruning of the installed list to rlist_inner with the coordinates on the device"""
+        self._chk(self.lib.nbnxn_hip_launch_kernel_pruneonly(self.h, iloc, rlist_inner, num_parts))
 
     # ---- pair search on the device (SURVEY 8f-2) ----
     def put_on_grid(self, box, x, type_, q, pbc_shift_dim=None, atom_density=0.0):

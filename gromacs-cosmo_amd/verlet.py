@@ -11,15 +11,20 @@
 
 x and f are caller-order device arrays (torch tensors); nothing but the energies crosses PCIe.
 The list is built with rlist >= rcoulomb and reused for nstlist steps, pruned by the first kernel
-that runs on it, as in the reference."""
+that runs on it, as in the reference.  With rlist_inner set, the list is instead re-pruned to that
+inner radius by the prune-only kernel (nbnxn_hip_launch_kernel_pruneonly): all of it on search
+steps, and on the other steps either all of it every nstprune steps (prune_parts = 1) or one of
+prune_parts slices every step (rolling)."""
 import numpy as np
 
 from . import abi
 
 
 class VerletLoop:
-    def __init__(self, nb, system, ip, nstlist=10, min_ci_balanced=None):
+    def __init__(self, nb, system, ip, nstlist=10, min_ci_balanced=None, rlist_inner=None, nstprune=0, prune_parts=1):
         self.nb, self.s, self.ip, self.nstlist = nb, system, ip, int(nstlist)
+        self.rlist_inner, self.nstprune, self.prune_parts = rlist_inner, int(nstprune), int(prune_parts)
+        assert rlist_inner is None or (ip.rcoulomb <= rlist_inner <= ip.rlist and (nstprune > 0 or prune_parts > 1))
         self.mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced
         nb.init_const(ip, system.ntype + 1, system.nbfp())
         self.box = np.ascontiguousarray(system.box, dtype=np.float32)
@@ -41,8 +46,15 @@ class VerletLoop:
         assert x.is_cuda and f.is_cuda and x.dtype == f.dtype and x.is_contiguous() and f.is_contiguous()
         if self.step % self.nstlist == 0:
             self.search(x)
+            if self.rlist_inner is not None:
+                nb.prune_only(self.rlist_inner, self.prune_parts)          # a new list: all of it
         else:
             nb.copy_x_to_xq(x.data_ptr())
+            if self.rlist_inner is not None:
+                if self.prune_parts > 1:
+                    nb.prune_only(self.rlist_inner, self.prune_parts)      # rolling: one slice per step
+                elif self.step % self.nstprune == 0:
+                    nb.prune_only(self.rlist_inner, 1)
         nb.clear_outputs(flags)
         nb.launch_kernel_resident(flags)
         nb.add_f(f.data_ptr())

@@ -486,6 +486,16 @@ int nbnxn_hip_download_coulomb_tab(nbnxn_hip_ptr_t nb, float *tab, int tab_alloc
 /* the HIP stream (hipStream_t) of a locality, as an opaque pointer */
 void *nbnxn_hip_get_stream(nbnxn_hip_ptr_t nb, int iloc);
 
+/* Dynamic pruning: re-prunes the list of iloc, built with the (outer) radius it was created with, to
+ * rlist_inner <= rlist using the coordinates now on the device; the force kernels then run on the
+ * inner list until the next call.  No counterpart in 5.0.4, whose lists are pruned once by their
+ * first force kernel (nbnxn_cuda_kernel.cuh:332-340); it is the nbnxn_gpu_launch_kernel_pruneonly of
+ * later GROMACS versions, named in SURVEY 8f-2.  The first call on a new list prunes all of it (and
+ * takes the place of the pruning force-kernel flavour); later calls prune one of num_parts slices
+ * of the entries in turn ("rolling": 1 = the whole list every call).  The caller chooses how many
+ * steps an inner list stays valid, as it does for the outer one. */
+int nbnxn_hip_launch_kernel_pruneonly(nbnxn_hip_ptr_t nb, int iloc, float rlist_inner, int num_parts);
+
 /* kernel only, no H2D: coordinates already resident. */
 int nbnxn_hip_launch_kernel_resident(nbnxn_hip_ptr_t nb, int flags, int iloc);
 

@@ -205,3 +205,72 @@ def test_verlet_loop_with_moving_atoms(nb, kind):
         assert abs(e[0] - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"]) and abs(e[1] - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"]), step
         x = x + vel
     assert loop.nsearch == 3
+
+
+def test_prune_only_kernel_equals_the_pruning_rule(nb):
+    """dynamic pruning: the outer list (rlist 1.1) re-pruned to 1.0 by the prune-only kernel, bit for bit the
+    masks of the reference's pruning rule (oracle_prune_list = nbnxn_cuda_kernel.cuh:332-340 at that radius);
+    then with moved atoms, one slice of three at a time"""
+    from gromacs_cosmo_amd.host import PairList
+    s = g.system.water_box(2, 2, 2)
+    ip = g.system.reaction_field(0.9, rlist=1.1)
+    p = g.workload.prepare(s, ip, 300)
+    g.workload.upload(nb, p, ip)
+    nb.upload_xq(p.xq)
+    nb.prune_only(1.0)                                       # first call on a new list: the whole list
+    got = nb.download_cj4(p.pl)["imei"]["imask"]
+    want = O.prune_list(p.xq, p.shift_vec, p.pl, 1.0)["imei"]["imask"]
+    assert np.array_equal(got, want) and (want != p.pl.cj4["imei"]["imask"]).any()
+    # the force kernel now runs on the inner list, without pruning flavour, and gives the same physics
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    f, e = nb.compute(p.xq, abi.FORCE_VIRIAL)
+    assert relrms(f, o["f"]) < FORCE_RTOL
+    assert np.array_equal(nb.download_cj4(p.pl)["imei"]["imask"], want)
+    # atoms move a little; rolling prune, slice by slice, from the OUTER masks (pruned at 1.1 with the old x)
+    rng = np.random.default_rng(1)
+    xq2 = p.xq.copy()
+    xq2[:, :3] += rng.normal(0, 0.02, (len(xq2), 3)).astype(np.float32)
+    nb.upload_xq(xq2)
+    outer = PairList(p.pl.sci, O.prune_list(p.xq, p.shift_vec, p.pl, 1.1), p.pl.excl, p.pl.nci_tot, 1.1)
+    want2 = O.prune_list(xq2, p.shift_vec, outer, 1.0)["imei"]["imask"]
+    assert (want2 != want).any()
+    nsci = p.pl.nsci
+    for part in range(3):
+        nb.prune_only(1.0, 3)
+        got2 = nb.download_cj4(p.pl)["imei"]["imask"]
+        done = np.zeros(p.pl.ncj4, dtype=bool)
+        for e_ in p.pl.sci[:nsci * (part + 1) // 3]:
+            done[e_["cj4_ind_start"]:e_["cj4_ind_end"]] = True
+        assert np.array_equal(got2[done], want2[done]) and np.array_equal(got2[~done], want[~done])
+    o2 = O.kernel_gpu_list(xq2, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    f2, _ = nb.compute(xq2, 0)
+    assert relrms(f2, o2["f"]) < FORCE_RTOL
+    with pytest.raises(RuntimeError):
+        nb.prune_only(1.2)                                   # beyond the radius the list was built with
+
+
+def test_verlet_loop_with_dynamic_pruning(nb):
+    """outer list 1.06 nm every 10 steps, rolling re-prune to 0.97 nm in 4 slices, cut-off 0.9: per-step
+    displacements bounded so that both buffers hold; every step's forces against a fresh exact list"""
+    import dataclasses
+    import torch
+    s = g.system.lj_chain_mixture(3000)
+    base = g.system.ewald(0.9)
+    ip = dataclasses.replace(base, rlist=1.06)
+    loop = g.verlet.VerletLoop(nb, s, ip, nstlist=10, min_ci_balanced=200, rlist_inner=0.97, prune_parts=4)
+    rng = np.random.default_rng(8)
+    x = s.x.copy()
+    vel = rng.uniform(-0.004, 0.004, x.shape).astype(np.float32)      # |v| <= 0.007 nm / step
+    for step in range(21):
+        if step % 10 == 0:
+            x = np.mod(x, s.box).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        fd = torch.zeros_like(xd)
+        loop.force(xd, fd, 0)
+        torch.cuda.synchronize()
+        p = g.workload.prepare(dataclasses.replace(s, x=np.mod(x, s.box).astype(np.float32)), base, 0)
+        o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, base, calc_ener=False)
+        fo = np.zeros((s.natoms, 3), dtype=np.float32)
+        p.host.add_f(np.asarray(o["f"], dtype=np.float32), fo)
+        assert relrms(fd.cpu().numpy(), fo) < FORCE_RTOL, step
+        x = x + vel
