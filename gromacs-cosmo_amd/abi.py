@@ -174,3 +174,9 @@ class GpuDevInfo(C.Structure):
 
 
 GPU_COMPATIBLE, GPU_NONEXISTENT, GPU_INCOMPATIBLE, GPU_INSANE = 0, 1, 2, 3
+
+
+class GridZone(C.Structure):
+    """nbx_grid_zone_t (include/nbnxn_hip.h)"""
+    _fields_ = [("corner0", C.c_float * 3), ("corner1", C.c_float * 3), ("a0", C.c_int), ("n", C.c_int),
+                ("atom_density", C.c_float)]

@@ -525,7 +525,8 @@ int cpyback_impl(nbnxn_hip *nb, float *h_f, int flags, int aloc)
     {
         HIP_TRY(hipMemcpyAsync(h_f + (size_t)begin * 3, nb->f.p + (size_t)begin * 3, (size_t)len * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     }
-    if (iloc == NBX_NONLOCAL) { HIP_TRY(hipEventRecord(nb->nonlocal_done, st)); }
+    // (one-stream handles run both localities in order on the same stream: nothing to signal)
+    if (iloc == NBX_NONLOCAL && nb->two_streams) { HIP_TRY(hipEventRecord(nb->nonlocal_done, st)); }
     if (iloc == NBX_LOCAL && ener)
     {
         HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->out, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1139,17 +1140,28 @@ int nbnxn_hip_set_atom_order(nbnxn_hip_ptr_t nb, int natoms_real, const int *a, 
 
 // ---- pair search on the device ----
 
-int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
-                          int x_on_device, const int *type, const float *q, float atom_density)
+int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int nzones,
+                                const nbx_grid_zone_t *zones, int natoms, const float *x, int x_on_device, const int *type,
+                                const float *q)
 {
     if (check_handle(nb)) { return 1; }
     if (!nb->have_const) { return nbx_fail("put_on_grid before init_const (the number of atom types comes from there)"); }
-    if (natoms <= 0 || !box || !x) { return nbx_fail("put_on_grid: missing atoms or box"); }
+    if (natoms <= 0 || !box || !x || !zones) { return nbx_fail("put_on_grid: missing atoms, box or zones"); }
+    if (nzones < 1 || nzones > 8) { return nbx_fail("put_on_grid: %d zones (a domain decomposition has 1 to 8)", nzones); }
     if ((type == nullptr) != (q == nullptr)) { return nbx_fail("put_on_grid: types and charges come together"); }
     // the topology does not change between searches: NULL type / q reuse the arrays of the last call
     if (!type && ((int)nb->d_type_in.n != natoms || (int)nb->d_q_in.n != natoms))
     {
         return nbx_fail("put_on_grid without types / charges, but none are held for %d atoms", natoms);
+    }
+    {
+        int a = 0;
+        for (int z = 0; z < nzones; z++)
+        {
+            if (zones[z].a0 != a || zones[z].n <= 0) { return nbx_fail("zone %d covers atoms [%d,%d): zones must tile [0,%d) in order", z, zones[z].a0, zones[z].a0 + zones[z].n, natoms); }
+            a += zones[z].n;
+        }
+        if (a != natoms) { return nbx_fail("the zones hold %d atoms, the call %d", a, natoms); }
     }
     HIP_TRY(hipSetDevice(nb->device));
     for (int i = 0; type && i < natoms; i++)
@@ -1173,21 +1185,28 @@ int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_
         HIP_TRY(hipMemcpyAsync(nb->d_q_in.p, q, (size_t)natoms * sizeof(float), hipMemcpyHostToDevice, st));
     }
     const int all_pbc[3] = {1, 1, 1};
-    if (nbx_search_grid_columns(nb->search, st, box, pbc_shift_dim ? pbc_shift_dim : all_pbc, natoms, d_x, atom_density))
+    for (int z = 0; z < nzones; z++)
     {
-        return nbx_fail("put_on_grid: %s", nbx_search_error());
+        if (nbx_search_grid_columns(nb->search, st, z, box, pbc_shift_dim ? pbc_shift_dim : all_pbc, zones[z].corner0, zones[z].corner1,
+                                    zones[z].a0, zones[z].n, d_x, zones[z].atom_density))
+        {
+            return nbx_fail("put_on_grid: %s", nbx_search_error());
+        }
     }
     const int npad = nbx_search_natoms_padded(nb->search);
     // what nbnxn_cuda_init_atomdata does for a new grid (nbnxn_cuda_data_mgmt.cu:853-912)
     bool re = false;
     if (dev_reserve(nb->xq, npad) || dev_reserve(nb->type, npad) || reserve_f(nb, (size_t)npad * 3, &re)) { return 1; }
-    nb->natoms = npad; nb->natoms_local = npad;
+    nb->natoms = npad; nb->natoms_local = nbx_search_natoms_padded_local(nb->search);
     nb->clean_other = false;
     if (re) { HIP_TRY(hipMemsetAsync(nb->f.p, 0, nb->f.alloc * sizeof(float), st)); }
     nb->plist[0].nsci = 0; nb->plist[1].nsci = 0;
-    if (nbx_search_grid_fill(nb->search, st, d_x, nb->d_q_in.p, nb->d_type_in.p, nb->ntype, nb->xq.p, nb->type.p))
+    for (int z = 0; z < nzones; z++)
     {
-        return nbx_fail("put_on_grid: %s", nbx_search_error());
+        if (nbx_search_grid_fill(nb->search, st, z, d_x, nb->d_q_in.p, nb->d_type_in.p, nb->ntype, nb->xq.p, nb->type.p))
+        {
+            return nbx_fail("put_on_grid: %s", nbx_search_error());
+        }
     }
     // the atom order for copy_x_to_xq / add_f, without a trip through the host
     if (dev_reserve(nb->d_a, npad) || dev_reserve(nb->d_cell, natoms) || dev_reserve(nb->d_x, (size_t)natoms * 3)
@@ -1221,10 +1240,21 @@ int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_
     return 0;
 }
 
+int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
+                          int x_on_device, const int *type, const float *q, float atom_density)
+{
+    if (!box) { return nbx_fail("put_on_grid: missing box"); }
+    nbx_grid_zone_t z;
+    for (int d = 0; d < 3; d++) { z.corner0[d] = 0; z.corner1[d] = box[d]; }
+    z.a0 = 0; z.n = natoms; z.atom_density = atom_density;
+    return nbnxn_hip_put_on_grid_zones(nb, box, pbc_shift_dim, 1, &z, natoms, x, x_on_device, type, q);
+}
+
 int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced)
 {
     if (check_handle(nb)) { return 1; }
-    if (iloc != NBX_LOCAL) { return nbx_fail("the device pair search builds the local list of the home zone only (iloc %d)", iloc); }
+    if (check_loc(iloc)) { return 1; }
+    if (iloc == NBX_NONLOCAL && nb->search && nbx_search_nzones(nb->search) < 2) { return nbx_fail("a non-local list needs halo zones on the grid (nbnxn_hip_put_on_grid_zones)"); }
     if (!nb->search || !nb->grid_on_device || nbx_search_natoms_padded(nb->search) != nb->natoms) { return nbx_fail("make_pairlist before put_on_grid (or after a new init_atomdata)"); }
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = nb->stream[0];
@@ -1246,7 +1276,7 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
         nb->excl_held = true;
     }
     nbx_search_list_t L;
-    if (nbx_search_make_pairlist(nb->search, st, rlist, min_ci_balanced, d_ei, d_ea, nb->xq.p, &L))
+    if (nbx_search_make_pairlist(nb->search, st, iloc, rlist, min_ci_balanced, d_ei, d_ea, nb->xq.p, &L))
     {
         return nbx_fail("make_pairlist: %s", nbx_search_error());
     }
@@ -1279,7 +1309,8 @@ int nbnxn_hip_download_grid(nbnxn_hip_ptr_t nb, int *dims, int *a, int *cell, fl
     HIP_TRY(hipSetDevice(nb->device));
     if (dims)
     {
-        if (nbx_search_grid_info(nb->search, &dims[0], &dims[1], &dims[2])) { return nbx_fail("download_grid: %s", nbx_search_error()); }
+        if (nbx_search_grid_info(nb->search, 0, &dims[0], &dims[1], &dims[2])) { return nbx_fail("download_grid: %s", nbx_search_error()); }
+        dims[2] = nb->natoms / 64;   // super-cells of all zones
         dims[3] = nb->natoms;
     }
     if (nbx_search_download_grid(nb->search, nb->stream[0], a, cell, bb, bbcz, nsubc)) { return nbx_fail("download_grid: %s", nbx_search_error()); }

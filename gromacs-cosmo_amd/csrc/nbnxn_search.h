@@ -14,18 +14,23 @@ void        nbx_search_destroy(nbx_search *s);
 // text of the last failure of a call that returned non-zero
 const char *nbx_search_error();
 
-// Stage 1 of nbnxn_put_on_grid (nbnxn_search.c:1777): column grid over [0, box) from the atom
-// density, atoms bucketed per column and ordered by z.  d_x is [n][3] in caller order, on the
-// device.  Synchronises the stream once (the padded atom count sizes the caller's arrays).
-int nbx_search_grid_columns(nbx_search *s, hipStream_t st, const float box[3], const int pbc_shift_dim[3], int n,
-                            const float *d_x, float atom_density);
-int nbx_search_natoms_padded(const nbx_search *s);
-// Stage 2: per super-cell ordering in y and x, bounding boxes, and the grid-ordered atom data
+// Stage 1 of nbnxn_put_on_grid (nbnxn_search.c:1777) for one zone: column grid over [corner0, corner1) from the
+// atom density, the zone's atoms d_x[a0 .. a0+n) bucketed per column and ordered by z.  Zones are gridded in order
+// (0 = home, then the halo zones as the domain decomposition numbers them); zone 0 starts a new search and takes the
+// box and the periodic dimensions.  d_x is [all atoms][3] in caller order, on the device.  Synchronises the stream
+// once (the padded atom count sizes the caller's arrays).  ALL zones get their columns before any is filled.
+int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[3], const int pbc_shift_dim[3],
+                            const float corner0[3], const float corner1[3], int a0, int n, const float *d_x, float atom_density);
+int nbx_search_natoms_padded(const nbx_search *s);         // all zones
+int nbx_search_natoms_padded_local(const nbx_search *s);   // home zone
+int nbx_search_nzones(const nbx_search *s);
+// Stage 2, per zone in order: per super-cell ordering in y and x, bounding boxes, and the grid-ordered atom data
 // (coordinates + charge with fillers, types with the dummy type): nbnxn_atomdata_set /
-// nbnxn_atomdata_copy_x_to_nbat_x of the reference folded into the gridding pass.
-int nbx_search_grid_fill(nbx_search *s, hipStream_t st, const float *d_x, const float *d_q, const int *d_type,
+// nbnxn_atomdata_copy_x_to_nbat_x of the reference folded into the gridding pass.  d_x / d_q / d_type hold all
+// atoms in caller order; d_xq / d_type_out are the grid-ordered arrays of all zones.
+int nbx_search_grid_fill(nbx_search *s, hipStream_t st, int zone, const float *d_x, const float *d_q, const int *d_type,
                          int ntype_with_dummy, float4 *d_xq, int *d_type_out);
-// device arrays: grid slot -> caller atom (-1 filler) [natoms_padded]; caller atom -> grid slot [n]
+// device arrays: grid slot -> caller atom (-1 filler) [natoms_padded]; caller atom -> grid slot [atoms of all zones]
 const int *nbx_search_atom_order(const nbx_search *s);
 const int *nbx_search_cell_index(const nbx_search *s);
 
@@ -36,13 +41,14 @@ struct nbx_search_list_t {
     const nbx_excl_t *excl;
 };
 
-// nbnxn_make_pairlist (nbnxn_search.c:5583) for the home zone: the local list in the GPU format,
-// left on the device.  d_excl_index [n+1] / d_excl_a: topology exclusions (t_blocka), may be null.
-int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min_ci_balanced, const int *d_excl_index,
+// nbnxn_make_pairlist (nbnxn_search.c:5583): iloc NBX_LOCAL = home zone against itself (half list), NBX_NONLOCAL =
+// home zone against the halo zones (all shifts); the list in the GPU format, left on the device until the next call.
+// d_excl_index [atoms+1] / d_excl_a: topology exclusions (t_blocka) in caller numbering, may be null.
+int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlist, int min_ci_balanced, const int *d_excl_index,
                              const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out);
 
 // verification: grid geometry and per-cluster data back on the host
-int nbx_search_grid_info(const nbx_search *s, int *ncx, int *ncy, int *nc);
+int nbx_search_grid_info(const nbx_search *s, int zone, int *ncx, int *ncy, int *nc);
 int nbx_search_download_grid(const nbx_search *s, hipStream_t st, int *a, int *cell, float *bb, float *bbcz, int *nsubc);
 
 // --- nbnxn_search_prims.hip: library scans / sorts behind plain signatures (hipCUB is heavy to

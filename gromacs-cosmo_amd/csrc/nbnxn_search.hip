@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -74,13 +75,30 @@ struct GridDims {
     float sx, sy, inv_sx, inv_sy;
 };
 
-struct ListParams {
-    GridDims g;
-    int      nc;
-    float    box[3];
-    int      shp[3];
-    float    rlist, rl2, rbb2;
+constexpr int MAX_ZONES = 8;   // a 3-D domain decomposition has at most 8 (domdec.c:433-449)
+
+// what the list kernels need to know about one j-zone
+struct ZoneParams {
+    GridDims   g;
+    const int *cxy_ind;   // column -> first super-cell, zone-local numbering
+    int        cell0;     // first super-cell of the zone in the global numbering
+    int        zr;        // index of the zone's z-range in zrange[]
+    float      rbb2;      // boundingbox_only_distance2 of (i-zone, this zone)
 };
+
+struct ListParams {
+    int        nci;       // super-cells of the i-zone (the home zone, cell0 = 0)
+    int        njz;       // j-zones of this list: 1 (the home zone itself) or the halo zones
+    int        same;      // the j-zone is the i-zone: half list, 14 shifts; otherwise all 27 shifts
+    float      box[3];
+    int        shp[3];
+    float      rlist, rl2;
+    ZoneParams zp[MAX_ZONES];
+};
+
+// Entry numbering, in the host builder's loop order: i super-cell, then j-zone, then shift (ascending shift
+// index = tz, ty, tx loops).  Within one grid only the 14 shifts <= CENTRAL are visited (one-way list).
+struct Entry { int sci, jzi, tx, ty, tz; };
 
 // the 14 shifts of a half list in ascending shift index (XYZ2IS, types/ishift.h:45-55), which is
 // the order the reference's tz / ty / tx loops visit them (nbnxn_search.c:5060-5096)
@@ -89,6 +107,28 @@ __device__ __constant__ signed char c_shift_t[NSHIFT_HALF][3] = {
     {-1, -1, 0},  {0, -1, 0},  {1, -1, 0},  {-1, 0, 0},  {0, 0, 0}};
 
 __device__ __forceinline__ int shift_index(int tx, int ty, int tz) { return 5 * (3 * (tz + 1) + ty + 1) + tx + 2; }
+
+__device__ __forceinline__ int entries_per_cell(int same, int njz) { return same ? NSHIFT_HALF : 27 * njz; }
+
+__device__ __forceinline__ Entry decode_entry(int e, int same, int njz)
+{
+    Entry     en;
+    const int per = entries_per_cell(same, njz);
+    en.sci        = e / per;
+    const int r   = e - en.sci * per;
+    if (same)
+    {
+        en.jzi = 0;
+        en.tx = c_shift_t[r][0]; en.ty = c_shift_t[r][1]; en.tz = c_shift_t[r][2];
+    }
+    else
+    {
+        en.jzi = r / 27;
+        const int ss = r - en.jzi * 27;
+        en.tx = ss % 3 - 1; en.ty = (ss / 3) % 3 - 1; en.tz = ss / 9 - 1;
+    }
+    return en;
+}
 
 // ------------------------------------------------------------------------------------------
 // gridding
@@ -103,20 +143,21 @@ __device__ __forceinline__ unsigned float_key_host_device(float v)
 // calc_column_indices: column of every atom (clamped: rounding at the upper edge), column
 // populations, and the sort key (column, z) whose stable sort reproduces "z ascending, ties by
 // atom index" of the host builder
-__global__ void k_columns(int n, const float *__restrict__ x, GridDims g, unsigned long long *__restrict__ key,
+__global__ void k_columns(int a0, int n, const float *__restrict__ x, GridDims g, unsigned long long *__restrict__ key,
                           int *__restrict__ val)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) { return; }
-    const float px = x[3 * i], py = x[3 * i + 1];
-    const float pz = x[3 * i + 2] + 0.0f;   // -0 -> +0: they compare equal and must sort as equal
+    const int   at = a0 + i;                // x holds all zones' atoms; this zone's start at a0
+    const float px = x[3 * at], py = x[3 * at + 1];
+    const float pz = x[3 * at + 2] + 0.0f;   // -0 -> +0: they compare equal and must sort as equal
     int         cx = (int)floorf((px - g.c0[0]) * g.inv_sx);
     int         cy = (int)floorf((py - g.c0[1]) * g.inv_sy);
     cx = min(max(cx, 0), g.ncx - 1);
     cy = min(max(cy, 0), g.ncy - 1);
     const int col = cx * g.ncy + cy;
     key[i]     = ((unsigned long long)(unsigned)col << 32) | float_key_host_device(pz);
-    val[i]     = i;
+    val[i]     = at;
 }
 
 // column populations from the sorted keys (no atomics, no contention on crowded columns): the
@@ -194,13 +235,14 @@ __device__ __forceinline__ void group_sort(SortItem &v, int lane)
 // cluster, the atom-order arrays and the grid-ordered atom data with fillers
 // (nbnxn_atomdata.c:288-295, 873, 937-951).
 __global__ void __launch_bounds__(64)
-k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, const int *__restrict__ cxy_na,
+k_supercells(int cell0, int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, const int *__restrict__ cxy_na,
              const int *__restrict__ atom_start, const int *__restrict__ sorted_atom, const float *__restrict__ x,
              const float *__restrict__ q, const int *__restrict__ type, int dummy_type, int *__restrict__ a_out,
              int *__restrict__ cell_out, float4 *__restrict__ xq, int *__restrict__ type_out, float *__restrict__ bb,
              float *__restrict__ bbcz, float *__restrict__ bbsc, int *__restrict__ nsubc, int *__restrict__ nsubc_tot)
 {
-    const int sc   = blockIdx.x;
+    const int sc   = blockIdx.x;          // zone-local; the per-cell arrays are indexed globally (cell0 + sc)
+    const int scg  = cell0 + sc;
     const int lane = threadIdx.x;
     if (sc >= nc) { return; }
     // the column that holds this super-cell: the last c with cxy_ind[c] <= sc (empty columns repeat an index)
@@ -248,7 +290,7 @@ k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, cons
     const bool cl_has_atoms = (cl_in_sc * NA_C) < na_c;
     if ((lane & 7) == 0)
     {
-        float *b = bb + ((size_t)sc * NSUBC + cl_in_sc) * 6;
+        float *b = bb + ((size_t)scg * NSUBC + cl_in_sc) * 6;
 #pragma unroll
         for (int d = 0; d < 3; d++)
         {
@@ -270,15 +312,15 @@ k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, cons
     if (lane == 0)
     {
         const int ns  = min(NSUBC, (na_c + NA_C - 1) / NA_C);
-        nsubc[sc]     = ns;
-        bbcz[2 * sc]     = z_first;
-        bbcz[2 * sc + 1] = z_last;
+        nsubc[scg]     = ns;
+        bbcz[2 * scg]     = z_first;
+        bbcz[2 * scg + 1] = z_last;
 #pragma unroll
-        for (int d = 0; d < 3; d++) { bbsc[6 * sc + d] = blo[d]; bbsc[6 * sc + 3 + d] = bhi[d]; }
+        for (int d = 0; d < 3; d++) { bbsc[6 * scg + d] = blo[d]; bbsc[6 * scg + 3 + d] = bhi[d]; }
         atomicAdd(nsubc_tot, ns);
     }
 
-    const size_t gi = (size_t)sc * NA_SC + lane;
+    const size_t gi = (size_t)scg * NA_SC + lane;
     a_out[gi]       = at;
     if (at >= 0)
     {
@@ -298,7 +340,7 @@ k_supercells(int nc, int ncxy, GridDims g, const int *__restrict__ cxy_ind, cons
 
 // z-range of all atoms as order-preserving keys: the cells of a column are ordered in z, so the first and
 // the last cell of every column suffice.  One block; zrange was initialised to {max key, 0}.
-__global__ void k_zrange(int ncxy, const int *__restrict__ cxy_ind, const float *__restrict__ bbcz, unsigned *__restrict__ zrange)
+__global__ void k_zrange(int cell0, int ncxy, const int *__restrict__ cxy_ind, const float *__restrict__ bbcz, unsigned *__restrict__ zrange)
 {
     unsigned kmin = 0xffffffffu, kmax = 0u;
     for (int c = threadIdx.x; c < ncxy; c += blockDim.x)
@@ -306,8 +348,8 @@ __global__ void k_zrange(int ncxy, const int *__restrict__ cxy_ind, const float 
         const int c0 = cxy_ind[c], c1 = cxy_ind[c + 1];
         if (c1 > c0)
         {
-            kmin = min(kmin, float_key(bbcz[2 * c0]));
-            kmax = max(kmax, float_key(bbcz[2 * (c1 - 1) + 1]));
+            kmin = min(kmin, float_key(bbcz[2 * (cell0 + c0)]));
+            kmax = max(kmax, float_key(bbcz[2 * (cell0 + c1 - 1) + 1]));
         }
     }
     atomicMin(&zrange[0], kmin);
@@ -341,7 +383,7 @@ __device__ __forceinline__ float bb_dist2(const float *a, const float *b)
 // as needing exclusion words, and the cluster pairs are counted into nci_tot.
 template <bool FILL>
 __global__ void __launch_bounds__(64)
-k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ nsubc, const float *__restrict__ bb,
+k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb,
        const float *__restrict__ bbcz, const float *__restrict__ bbsc, const unsigned *__restrict__ zrange,
        const float4 *__restrict__ xq, int *__restrict__ ncj,
        const int *__restrict__ cj4_start, nbx_cj4_t *__restrict__ cj4, int *__restrict__ need_excl,
@@ -349,9 +391,11 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
 {
     const int e    = blockIdx.x;
     const int lane = threadIdx.x;
-    const int sci  = e / NSHIFT_HALF;
-    const int ss   = e - sci * NSHIFT_HALF;
-    const int tx = c_shift_t[ss][0], ty = c_shift_t[ss][1], tz = c_shift_t[ss][2];
+    const Entry en = decode_entry(e, P.same, P.njz);
+    const int   sci = en.sci, tx = en.tx, ty = en.ty, tz = en.tz;
+    const ZoneParams &Z = P.zp[en.jzi];
+    const int *__restrict__ cxy_ind = Z.cxy_ind;
+    const int   cell0 = Z.cell0;          // j super-cells: zone-local index + cell0 = global index
     const int nsub_i = nsubc[sci];
     const bool active = nsub_i > 0 && abs(tx) <= P.shp[0] && abs(ty) <= P.shp[1] && abs(tz) <= P.shp[2];
     if (!active)
@@ -361,13 +405,13 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
     }
     const int   shift = shift_index(tx, ty, tz);
     const float sh[3] = {tx * P.box[0], ty * P.box[1], tz * P.box[2]};
-    const bool  central = (shift == NBX_CENTRAL);
+    const bool  central = P.same && (shift == NBX_CENTRAL);   // half list only within one grid
 
     // box of the whole i super-cell (unshifted union of its clusters' boxes, from the gridding pass), then shifted
     float bS[6];
 #pragma unroll
     for (int d = 0; d < 3; d++) { bS[d] = bbsc[6 * sci + d] + sh[d]; bS[3 + d] = bbsc[6 * sci + 3 + d] + sh[d]; }
-    const GridDims &g = P.g;
+    const GridDims &g = Z.g;
     int cxf = (int)floorf((bS[0] - P.rlist - g.c0[0]) * g.inv_sx);
     int cxl = (int)floorf((bS[3] + P.rlist - g.c0[0]) * g.inv_sx);
     int cyf = (int)floorf((bS[1] - P.rlist - g.c0[1]) * g.inv_sy);
@@ -379,7 +423,7 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
     // (0.1 % of rlist + 1e-3 nm) far above float rounding: when the shifted cell is further than that from every
     // atom, the exact z-test below would reject every cell of every column as well, so the list is unchanged.
     const float zmargin = P.rlist * 1.001f + 1e-3f;
-    const bool  none_in_z = (bS[5] + zmargin < key_float(zrange[0])) || (bS[2] - zmargin > key_float(zrange[1]));
+    const bool  none_in_z = (bS[5] + zmargin < key_float(zrange[2 * Z.zr])) || (bS[2] - zmargin > key_float(zrange[2 * Z.zr + 1]));
     if (cxf > cxl || cyf > cyl || none_in_z)
     {
         if (!FILL && lane == 0) { ncj[e] = 0; }
@@ -436,7 +480,7 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
                 while (a < b)
                 {
                     const int   mid = (a + b) >> 1;
-                    const float z1  = bbcz[2 * mid + 1];
+                    const float z1  = bbcz[2 * (cell0 + mid) + 1];
                     if (z1 < bS[2] && d2xy + sqr(bS[2] - z1) >= P.rl2) { a = mid + 1; } else { b = mid; }
                 }
                 my_lo = a;
@@ -444,7 +488,7 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
                 while (a < b)
                 {
                     const int   mid = (a + b) >> 1;
-                    const float z0  = bbcz[2 * mid];
+                    const float z0  = bbcz[2 * (cell0 + mid)];
                     if (z0 > bS[5] && d2xy + sqr(z0 - bS[5]) >= P.rl2) { b = mid; } else { a = mid + 1; }
                 }
                 my_hi   = a;
@@ -461,15 +505,15 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
                 const int scj = cb + (lane >> 3);
                 const int cjo = lane & 7;
                 unsigned  mb  = 0;
-                if (scj < z_hi && cjo < nsubc[scj])
+                if (scj < z_hi && cjo < nsubc[cell0 + scj])
                 {
                     float       d2 = d2xy;
-                    const float z0 = bbcz[2 * scj], z1 = bbcz[2 * scj + 1];
+                    const float z0 = bbcz[2 * (cell0 + scj)], z1 = bbcz[2 * (cell0 + scj) + 1];
                     if (z0 > bS[5]) { d2 += sqr(z0 - bS[5]); }
                     else if (z1 < bS[2]) { d2 += sqr(bS[2] - z1); }
                     if (d2 < P.rl2)
                     {
-                        const int cj = scj * NSUBC + cjo;
+                        const int cj = (cell0 + scj) * NSUBC + cjo;
                         float     bj[6];
 #pragma unroll
                         for (int w = 0; w < 6; w++) { bj[w] = bb[(size_t)cj * 6 + w]; }
@@ -482,7 +526,7 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
                             if (d2c < P.rl2) { mb |= 1u << ci; ci_last = ci; d2_last = d2c; np++; }
                         }
                         // a lone cluster pair beyond the box-only radius gets the atom check (:3073-3092)
-                        if (np == 1 && d2_last >= P.rbb2)
+                        if (np == 1 && d2_last >= Z.rbb2)
                         {
                             // all eight j-atoms are requested at once (a loop with an early exit would wait for
                             // them one by one); "any pair in range" does not depend on the order of the tests
@@ -508,7 +552,7 @@ k_list(ListParams P, const int *__restrict__ cxy_ind, const int *__restrict__ ns
                 {
                     const int slot = running + __popcll(kept & ((1ull << lane) - 1ull));
                     nbx_cj4_t *grp = cj4 + base4 + (slot >> 2);
-                    grp->cj[slot & 3] = scj * NSUBC + cjo;
+                    grp->cj[slot & 3] = (cell0 + scj) * NSUBC + cjo;
                     reinterpret_cast<unsigned char *>(&grp->imei[0].imask)[slot & 3] = (unsigned char)mb;
                     reinterpret_cast<unsigned char *>(&grp->imei[1].imask)[slot & 3] = (unsigned char)mb;
                     if (central && sci == scj)
@@ -545,7 +589,7 @@ __device__ __forceinline__ int cj_at(const nbx_cj4_t *cj4, int ind) { return cj4
 // the j > i masks of the entry's own clusters, set_self_and_newton_excls_supersub).
 template <bool APPLY>
 __global__ void __launch_bounds__(64)
-k_excl(int natoms, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
+k_excl(int natoms, int same, int njz, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
        const int *__restrict__ a, const int *__restrict__ cell, const int *__restrict__ excl_index,
        const int *__restrict__ excl_a, int *__restrict__ need_excl, nbx_excl_t *__restrict__ excl)
 {
@@ -553,9 +597,9 @@ k_excl(int natoms, const int *__restrict__ ncj, const int *__restrict__ cj4_star
     const int lane = threadIdx.x;
     const int n    = ncj[e];
     if (n == 0) { return; }
-    const int  sci     = e / NSHIFT_HALF;
-    const int  ss      = e - sci * NSHIFT_HALF;
-    const bool central = shift_index(c_shift_t[ss][0], c_shift_t[ss][1], c_shift_t[ss][2]) == NBX_CENTRAL;
+    const Entry en     = decode_entry(e, same, njz);
+    const int  sci     = en.sci;
+    const bool central = same && shift_index(en.tx, en.ty, en.tz) == NBX_CENTRAL;
     const int  first   = cj4_start[e] * 4, last = first + n - 1;
 
     if (APPLY && central)
@@ -634,7 +678,7 @@ __global__ void k_excl_init(int n2, const int *__restrict__ need_excl, const int
 // split_sci_entry, one thread per entry.  WRITE = false: nparts[e]; WRITE = true: the entry's
 // nbnxn_sci_t parts at part_start[e].
 template <bool WRITE>
-__global__ void k_split(int nentries, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
+__global__ void k_split(int nentries, int same, int njz, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
                         const nbx_cj4_t *__restrict__ cj4, int nsp_max, int *__restrict__ nparts,
                         const int *__restrict__ part_start, nbx_sci_t *__restrict__ sci_out)
 {
@@ -643,9 +687,9 @@ __global__ void k_split(int nentries, const int *__restrict__ ncj, const int *__
     if (e == nentries) { if (!WRITE) { nparts[e] = 0; } return; }
     const int n = ncj[e];
     if (n == 0) { if (!WRITE) { nparts[e] = 0; } return; }
-    const int sci   = e / NSHIFT_HALF;
-    const int ss    = e - sci * NSHIFT_HALF;
-    const int shift = shift_index(c_shift_t[ss][0], c_shift_t[ss][1], c_shift_t[ss][2]);
+    const Entry en  = decode_entry(e, same, njz);
+    const int sci   = en.sci;
+    const int shift = shift_index(en.tx, en.ty, en.tz);
     const int start = cj4_start[e], end = start + ((n + 3) >> 2);
     const int j4len = end - start;
     int       count = 0;
@@ -704,18 +748,32 @@ inline int blocks_for(size_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 } // namespace
 
-struct nbx_search {
-    float    box[3] = {0, 0, 0};
-    int      shp[3] = {1, 1, 1};
-    int      natoms = 0, nc = 0, ncxy = 0, nsubc_tot = 0;
-    float    density = 0;
+struct Zone {
     GridDims g;
-    bool     have_columns = false, have_grid = false;
-    // gridding
-    Buf<int>                cxy_na, ncz, cxy_ind, atom_start, val_in, sorted_atom, a, cell, nsubc, counters;
+    int      a0 = 0, n = 0, cell0 = 0, nc = 0, ncxy = 0;
+    float    density = 0;
+    float    c1[3] = {0, 0, 0};
+    Buf<int>                cxy_na, ncz, cxy_ind, atom_start, val_in, sorted_atom;
     Buf<unsigned long long> key_in, key_out;
-    Buf<float>              bb, bbcz, bbsc;
-    Buf<unsigned>           zrange;
+    void release()
+    {
+        cxy_na.release(); ncz.release(); cxy_ind.release(); atom_start.release(); val_in.release(); sorted_atom.release();
+        key_in.release(); key_out.release();
+    }
+};
+
+struct nbx_search {
+    float box[3] = {0, 0, 0};
+    int   shp[3] = {1, 1, 1};
+    int   nzones = 0, nzones_filled = 0;
+    int   natoms = 0;      // atoms of all zones gridded so far
+    int   nc     = 0;      // super-cells of all zones
+    int   nsubc_tot0 = -1; // clusters with atoms in the home zone (read back when a list needs it)
+    Zone  zone[MAX_ZONES];
+    // per super-cell / cluster / atom, all zones, global numbering
+    Buf<int>      a, cell, nsubc, counters;
+    Buf<float>    bb, bbcz, bbsc;
+    Buf<unsigned> zrange;
     // list
     Buf<int>        ncj, ncj4_e, cj4_start, need_excl, excl_rank, nparts, part_start;
     Buf<nbx_cj4_t>  cj4;
@@ -730,9 +788,9 @@ nbx_search *nbx_search_create() { return new nbx_search(); }
 void nbx_search_destroy(nbx_search *s)
 {
     if (!s) { return; }
-    s->cxy_na.release(); s->ncz.release(); s->cxy_ind.release(); s->atom_start.release(); s->val_in.release();
-    s->sorted_atom.release(); s->a.release(); s->cell.release(); s->nsubc.release(); s->counters.release();
-    s->key_in.release(); s->key_out.release(); s->bb.release(); s->bbcz.release(); s->bbsc.release(); s->zrange.release();
+    for (Zone &z : s->zone) { z.release(); }
+    s->a.release(); s->cell.release(); s->nsubc.release(); s->counters.release();
+    s->bb.release(); s->bbcz.release(); s->bbsc.release(); s->zrange.release();
     s->ncj.release(); s->ncj4_e.release(); s->cj4_start.release(); s->need_excl.release(); s->excl_rank.release();
     s->nparts.release(); s->part_start.release(); s->cj4.release(); s->excl.release(); s->sci_a.release(); s->sci_b.release();
     s->skey_in.release(); s->skey_out.release();
@@ -742,93 +800,115 @@ void nbx_search_destroy(nbx_search *s)
 
 const char *nbx_search_error() { return g_err.c_str(); }
 
-int nbx_search_grid_columns(nbx_search *s, hipStream_t st, const float box[3], const int pbc_shift_dim[3], int n,
-                            const float *d_x, float atom_density)
+int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[3], const int pbc_shift_dim[3],
+                            const float corner0[3], const float corner1[3], int a0, int n, const float *d_x, float atom_density)
 {
     if (!s) { return sfail("null search handle"); }
-    if (n <= 0 || !d_x) { return sfail("put_on_grid needs atoms"); }
+    if (zone < 0 || zone >= MAX_ZONES) { return sfail("zone %d outside [0,%d)", zone, MAX_ZONES); }
+    if (zone == 0)
+    {
+        for (int d = 0; d < 3; d++)
+        {
+            if (!(box[d] > 0)) { return sfail("box[%d] = %g must be > 0", d, box[d]); }
+            s->box[d] = box[d];
+            s->shp[d] = pbc_shift_dim[d] ? 1 : 0;
+        }
+        s->nzones = 0; s->nzones_filled = 0; s->natoms = 0; s->nc = 0; s->nsubc_tot0 = -1;
+        if (s->counters.reserve(16)) { return 1; }
+        S_TRY(hipMemsetAsync(s->counters.p, 0, 16 * sizeof(int), st));
+    }
+    if (zone != s->nzones) { return sfail("zones must be gridded in order: got %d, expected %d", zone, s->nzones); }
+    if (s->nzones_filled != 0) { return sfail("all zones get their columns before the first one is filled"); }
+    if (n <= 0 || !d_x) { return sfail("zone %d has no atoms", zone); }
+    if (a0 != s->natoms) { return sfail("zone %d starts at atom %d but %d atoms are gridded", zone, a0, s->natoms); }
+    Zone &z = s->zone[zone];
+    float size[3];
     for (int d = 0; d < 3; d++)
     {
-        if (!(box[d] > 0)) { return sfail("box[%d] = %g must be > 0", d, box[d]); }
-        s->box[d] = box[d];
-        s->shp[d] = pbc_shift_dim[d] ? 1 : 0;
+        z.g.c0[d] = corner0[d];
+        z.c1[d]   = corner1[d];
+        size[d]   = corner1[d] - corner0[d];
+        if (!(size[d] > 0)) { return sfail("zone %d has no extent along %d", zone, d); }
     }
-    s->have_columns = s->have_grid = false;
-    s->natoms = n;
     // set_grid_size_xy (:433-486): columns of 2x2 roughly cubic sub-cells, as the host builder sizes them
-    if (atom_density <= 0) { atom_density = std::max(n, 1) / (box[0] * box[1] * box[2]); }
-    s->density = atom_density;
-    GridDims &g = s->g;
-    g.c0[0] = g.c0[1] = g.c0[2] = 0;
+    if (atom_density <= 0) { atom_density = std::max(n, 1) / (size[0] * size[1] * size[2]); }
+    z.density = atom_density;
+    GridDims &g = z.g;
     if (n > NA_SC)
     {
         const float tlen = std::cbrt(NA_C / atom_density);
-        g.ncx = std::max(1, (int)(box[0] / (tlen * 2)));
-        g.ncy = std::max(1, (int)(box[1] / (tlen * 2)));
+        g.ncx = std::max(1, (int)(size[0] / (tlen * 2)));
+        g.ncy = std::max(1, (int)(size[1] / (tlen * 2)));
     }
     else { g.ncx = 1; g.ncy = 1; }
-    g.sx = box[0] / g.ncx; g.inv_sx = 1 / g.sx;
-    g.sy = box[1] / g.ncy; g.inv_sy = 1 / g.sy;
+    g.sx = size[0] / g.ncx; g.inv_sx = 1 / g.sx;
+    g.sy = size[1] / g.ncy; g.inv_sy = 1 / g.sy;
     const int ncxy = g.ncx * g.ncy;
-    s->ncxy = ncxy;
+    z.ncxy = ncxy; z.a0 = a0; z.n = n;
 
-    if (s->cxy_na.reserve(ncxy + 1) || s->ncz.reserve(ncxy + 1) || s->cxy_ind.reserve(ncxy + 1) || s->atom_start.reserve(ncxy + 1)
-        || s->key_in.reserve(n) || s->key_out.reserve(n) || s->val_in.reserve(n) || s->sorted_atom.reserve(n)
-        || s->counters.reserve(8)) { return 1; }
-    S_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(int), st));
-    hipLaunchKernelGGL(k_columns, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, d_x, g, s->key_in.p, s->val_in.p);
+    if (z.cxy_na.reserve(ncxy + 1) || z.ncz.reserve(ncxy + 1) || z.cxy_ind.reserve(ncxy + 1) || z.atom_start.reserve(ncxy + 1)
+        || z.key_in.reserve(n) || z.key_out.reserve(n) || z.val_in.reserve(n) || z.sorted_atom.reserve(n)) { return 1; }
+    hipLaunchKernelGGL(k_columns, dim3(blocks_for(n, 256)), dim3(256), 0, st, a0, n, d_x, g, z.key_in.p, z.val_in.p);
     S_TRY(hipGetLastError());
     int col_bits = 1;
     while ((1 << col_bits) < ncxy) { col_bits++; }
-    S_TRY(nbx_prim_sort_u64_int(s->tmp, s->key_in.p, s->key_out.p, s->val_in.p, s->sorted_atom.p, n, 32 + col_bits, st));
-    hipLaunchKernelGGL(k_column_cells, dim3(blocks_for(ncxy + 1, 256)), dim3(256), 0, st, ncxy, n, s->key_out.p, s->cxy_na.p, s->ncz.p);
+    S_TRY(nbx_prim_sort_u64_int(s->tmp, z.key_in.p, z.key_out.p, z.val_in.p, z.sorted_atom.p, n, 32 + col_bits, st));
+    hipLaunchKernelGGL(k_column_cells, dim3(blocks_for(ncxy + 1, 256)), dim3(256), 0, st, ncxy, n, z.key_out.p, z.cxy_na.p, z.ncz.p);
     S_TRY(hipGetLastError());
-    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncz.p, s->cxy_ind.p, ncxy + 1, st));
-    S_TRY(nbx_prim_exclusive_sum(s->tmp, s->cxy_na.p, s->atom_start.p, ncxy + 1, st));
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, z.ncz.p, z.cxy_ind.p, ncxy + 1, st));
+    S_TRY(nbx_prim_exclusive_sum(s->tmp, z.cxy_na.p, z.atom_start.p, ncxy + 1, st));
     int nc = 0;
-    S_TRY(hipMemcpyAsync(&nc, s->cxy_ind.p + ncxy, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&nc, z.cxy_ind.p + ncxy, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
-    s->nc = nc;
-    s->have_columns = true;
+    z.nc    = nc;
+    z.cell0 = s->nc;
+    s->nc += nc;
+    s->natoms += n;
+    s->nzones = zone + 1;
     return 0;
 }
 
-int nbx_search_natoms_padded(const nbx_search *s) { return s && s->have_columns ? s->nc * NA_SC : -1; }
+int nbx_search_natoms_padded(const nbx_search *s) { return s && s->nzones > 0 ? s->nc * NA_SC : -1; }
+int nbx_search_natoms_padded_local(const nbx_search *s) { return s && s->nzones > 0 ? s->zone[0].nc * NA_SC : -1; }
+int nbx_search_nzones(const nbx_search *s) { return s ? s->nzones : 0; }
 
-int nbx_search_grid_fill(nbx_search *s, hipStream_t st, const float *d_x, const float *d_q, const int *d_type,
+int nbx_search_grid_fill(nbx_search *s, hipStream_t st, int zone, const float *d_x, const float *d_q, const int *d_type,
                          int ntype_with_dummy, float4 *d_xq, int *d_type_out)
 {
-    if (!s || !s->have_columns) { return sfail("grid_fill before grid_columns"); }
-    const size_t npad = (size_t)s->nc * NA_SC;
-    if (s->a.reserve(npad) || s->cell.reserve(s->natoms) || s->nsubc.reserve(s->nc) || s->bb.reserve((size_t)s->nc * NSUBC * 6)
-        || s->bbcz.reserve((size_t)s->nc * 2) || s->bbsc.reserve((size_t)s->nc * 6) || s->zrange.reserve(2)) { return 1; }
+    if (!s || zone < 0 || zone >= s->nzones) { return sfail("grid_fill of zone %d before its grid_columns", zone); }
+    if (zone != s->nzones_filled) { return sfail("zones are filled in order: got %d, expected %d", zone, s->nzones_filled); }
+    if (zone == 0)
     {
-        static const unsigned init[2] = {0xffffffffu, 0u};
+        const size_t npad = (size_t)s->nc * NA_SC;
+        if (s->a.reserve(npad) || s->cell.reserve(s->natoms) || s->nsubc.reserve(s->nc) || s->bb.reserve((size_t)s->nc * NSUBC * 6)
+            || s->bbcz.reserve((size_t)s->nc * 2) || s->bbsc.reserve((size_t)s->nc * 6) || s->zrange.reserve(2 * MAX_ZONES)) { return 1; }
+        static const unsigned init[2 * MAX_ZONES] = {0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u,
+                                                     0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u};
         S_TRY(hipMemcpyAsync(s->zrange.p, init, sizeof(init), hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_supercells, dim3(s->nc), dim3(64), 0, st, s->nc, s->ncxy, s->g, s->cxy_ind.p, s->cxy_na.p, s->atom_start.p,
-                       s->sorted_atom.p, d_x, d_q, d_type, ntype_with_dummy - 1, s->a.p, s->cell.p, d_xq, d_type_out, s->bb.p,
-                       s->bbcz.p, s->bbsc.p, s->nsubc.p, s->counters.p);
-    hipLaunchKernelGGL(k_zrange, dim3(1), dim3(256), 0, st, s->ncxy, s->cxy_ind.p, s->bbcz.p, s->zrange.p);
+    Zone &z = s->zone[zone];
+    hipLaunchKernelGGL(k_supercells, dim3(z.nc), dim3(64), 0, st, z.cell0, z.nc, z.ncxy, z.g, z.cxy_ind.p, z.cxy_na.p, z.atom_start.p,
+                       z.sorted_atom.p, d_x, d_q, d_type, ntype_with_dummy - 1, s->a.p, s->cell.p, d_xq, d_type_out, s->bb.p,
+                       s->bbcz.p, s->bbsc.p, s->nsubc.p, s->counters.p + 2 + zone);
+    hipLaunchKernelGGL(k_zrange, dim3(1), dim3(256), 0, st, z.cell0, z.ncxy, z.cxy_ind.p, s->bbcz.p, s->zrange.p + 2 * zone);
     S_TRY(hipGetLastError());
-    s->have_grid = true;
-    s->nsubc_tot = -1;   // read back when the list needs it
+    s->nzones_filled = zone + 1;
     return 0;
 }
 
 const int *nbx_search_atom_order(const nbx_search *s) { return s->a.p; }
 const int *nbx_search_cell_index(const nbx_search *s) { return s->cell.p; }
 
-int nbx_search_grid_info(const nbx_search *s, int *ncx, int *ncy, int *nc)
+int nbx_search_grid_info(const nbx_search *s, int zone, int *ncx, int *ncy, int *nc)
 {
-    if (!s || !s->have_columns) { return sfail("no grid"); }
-    *ncx = s->g.ncx; *ncy = s->g.ncy; *nc = s->nc;
+    if (!s || zone < 0 || zone >= s->nzones) { return sfail("no such zone"); }
+    *ncx = s->zone[zone].g.ncx; *ncy = s->zone[zone].g.ncy; *nc = s->zone[zone].nc;
     return 0;
 }
 
 int nbx_search_download_grid(const nbx_search *s, hipStream_t st, int *a, int *cell, float *bb, float *bbcz, int *nsubc)
 {
-    if (!s || !s->have_grid) { return sfail("no grid"); }
+    if (!s || s->nzones == 0 || s->nzones_filled != s->nzones) { return sfail("no grid"); }
     if (a) { S_TRY(hipMemcpyAsync(a, s->a.p, (size_t)s->nc * NA_SC * sizeof(int), hipMemcpyDeviceToHost, st)); }
     if (cell) { S_TRY(hipMemcpyAsync(cell, s->cell.p, (size_t)s->natoms * sizeof(int), hipMemcpyDeviceToHost, st)); }
     if (bb) { S_TRY(hipMemcpyAsync(bb, s->bb.p, (size_t)s->nc * NSUBC * 6 * sizeof(float), hipMemcpyDeviceToHost, st)); }
@@ -840,14 +920,15 @@ int nbx_search_download_grid(const nbx_search *s, hipStream_t st, int *a, int *c
 
 namespace {
 
-// get_nsubpair_max (nbnxn_search.c:4324-4408), single-grid estimate, as in the host builder
-int nsubpair_max(const nbx_search &s, float rlist, int min_ci_balanced)
+// get_nsubpair_max (nbnxn_search.c:4324-4408), estimate from the home grid, as in the host builder
+int nsubpair_max(const nbx_search &s, float rlist, int min_ci_balanced, double frac_of_local)
 {
-    if (min_ci_balanced <= 0 || s.nc >= min_ci_balanced || s.nc == 0) { return -1; }
+    const Zone &z = s.zone[0];
+    if (min_ci_balanced <= 0 || z.nc >= min_ci_balanced || z.nc == 0) { return -1; }
     double ls[3];
-    ls[0] = s.box[0] / (s.g.ncx * 2);
-    ls[1] = s.box[1] / (s.g.ncy * 2);
-    ls[2] = s.box[2] * s.g.ncx * s.g.ncy / (s.nc * 2.0);
+    ls[0] = (z.c1[0] - z.g.c0[0]) / (z.g.ncx * 2);
+    ls[1] = (z.c1[1] - z.g.c0[1]) / (z.g.ncy * 2);
+    ls[2] = (z.c1[2] - z.g.c0[2]) * z.g.ncx * z.g.ncy / (z.nc * 2.0);
     const double diag2 = ls[0] * ls[0] + ls[1] * ls[1] + ls[2] * ls[2];
     const float  f     = (NA_C - 1.0f) / NA_C;
     const double r_eff = rlist + 0.5 * (f * f) * std::sqrt(diag2 / 3);
@@ -855,18 +936,26 @@ int nsubpair_max(const nbx_search &s, float rlist, int min_ci_balanced)
     vol += (ls[0] * ls[1] + ls[0] * ls[2] + ls[1] * ls[2]) * r_eff;
     vol += 2 * (ls[0] + ls[1] + ls[2]) * 0.25 * M_PI * r_eff * r_eff;
     vol += 0.5 * 4.0 / 3.0 * M_PI * r_eff * r_eff * r_eff;
-    const double nsp_est = s.nsubc_tot * vol * s.density / NA_C;
+    const double nsp_est = s.nsubc_tot0 * vol * z.density / NA_C * frac_of_local;
     const int    nsp     = std::max(1, (int)(nsp_est / min_ci_balanced + 0.5));
     return nsp + NSUBC * 4 / 2;
 }
 
 } // namespace
 
-int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min_ci_balanced, const int *d_excl_index,
+int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlist, int min_ci_balanced, const int *d_excl_index,
                              const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out)
 {
-    if (!s || !s->have_grid) { return sfail("no grid: put the atoms on the grid first"); }
+    if (!s || s->nzones == 0 || s->nzones_filled != s->nzones) { return sfail("no grid: put the atoms on the grid first"); }
     if (!(rlist > 0)) { return sfail("rlist must be > 0"); }
+    const bool same = (iloc == NBX_LOCAL);
+    if (!same && s->nzones < 2)
+    {
+        // no halo zone: an empty non-local list
+        out->nsci = out->ncj4 = out->nci_tot = 0; out->nexcl = 0;
+        out->sci = nullptr; out->cj4 = nullptr; out->excl = nullptr;
+        return 0;
+    }
     for (int d = 0; d < 3; d++)
     {
         if (s->shp[d] && s->box[d] < 2 * rlist)
@@ -874,44 +963,53 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min
             return sfail("box[%d] = %g is shorter than 2*rlist = %g: more than one periodic image in range", d, s->box[d], 2 * rlist);
         }
     }
-    ListParams P;
-    P.g = s->g; P.nc = s->nc;
+    const Zone &zi = s->zone[0];
+    ListParams  P;
+    memset(&P, 0, sizeof(P));
+    P.nci  = zi.nc;
+    P.same = same ? 1 : 0;
+    P.njz  = same ? 1 : s->nzones - 1;
     for (int d = 0; d < 3; d++) { P.box[d] = s->box[d]; P.shp[d] = s->shp[d]; }
     P.rlist = rlist;
     P.rl2   = rlist * rlist;
+    for (int k = 0; k < P.njz; k++)
     {
+        const int   zid = same ? 0 : k + 1;
+        const Zone &zj  = s->zone[zid];
+        ZoneParams &zp  = P.zp[k];
+        zp.g = zj.g; zp.cxy_ind = zj.cxy_ind.p; zp.cell0 = zj.cell0; zp.zr = zid;
         // boundingbox_only_distance2 (:4721-4757), float arithmetic as in the host builder
-        const float bbx = 0.5f * (s->g.sx + s->g.sx) / 2, bby = 0.5f * (s->g.sy + s->g.sy) / 2;
+        const float bbx = 0.5f * (zi.g.sx + zj.g.sx) / 2, bby = 0.5f * (zi.g.sy + zj.g.sy) / 2;
         const float r   = std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby));
-        P.rbb2 = r * r;
+        zp.rbb2 = r * r;
     }
-    const int nent = s->nc * NSHIFT_HALF;
-    int      *cnt  = s->counters.p;   // [0] nsubc_tot (from gridding), [1] nci_tot
+    const int nent = zi.nc * (same ? NSHIFT_HALF : 27 * P.njz);
+    int      *cnt  = s->counters.p;   // [1] nci_tot of the list being made, [2 + z] clusters with atoms of zone z
 
     if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)
         || s->part_start.reserve(nent + 1)) { return 1; }
     S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));
-    hipLaunchKernelGGL((k_list<false>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
+    hipLaunchKernelGGL((k_list<false>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
                        (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)nullptr);
     hipLaunchKernelGGL(k_groups_of, dim3(blocks_for(nent + 1, 256)), dim3(256), 0, st, nent, s->ncj.p, s->ncj4_e.p);
     S_TRY(hipGetLastError());
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncj4_e.p, s->cj4_start.p, nent + 1, st));
     int h1[2] = {0, 0};
     S_TRY(hipMemcpyAsync(&h1[0], s->cj4_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
-    S_TRY(hipMemcpyAsync(&h1[1], cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&h1[1], cnt + 2, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
-    const int ncj4 = h1[0];
-    s->nsubc_tot   = h1[1];
-    const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced);
+    const int ncj4  = h1[0];
+    s->nsubc_tot0   = h1[1];
+    const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced, same ? 1.0 : 0.25);
 
     if (s->cj4.reserve((size_t)ncj4 + 1) || s->need_excl.reserve(2 * (size_t)ncj4 + 1) || s->excl_rank.reserve(2 * (size_t)ncj4 + 1)) { return 1; }
     S_TRY(hipMemsetAsync(s->cj4.p, 0, ((size_t)ncj4 + 1) * sizeof(nbx_cj4_t), st));
     S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
-    hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->cxy_ind.p, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
+    hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
                        s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1));
-    hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+    hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
-    hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, s->ncj.p, s->cj4_start.p, s->cj4.p,
+    hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p,
                        nsp_max, s->nparts.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
     S_TRY(hipGetLastError());
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->need_excl.p, s->excl_rank.p, 2 * ncj4 + 1, st));
@@ -927,9 +1025,9 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, float rlist, int min
         || s->skey_out.reserve((size_t)nsci + 1)) { return 1; }
     hipLaunchKernelGGL(k_excl_init, dim3(blocks_for(2 * (size_t)ncj4 + 1, 256)), dim3(256), 0, st, 2 * ncj4, s->need_excl.p, s->excl_rank.p,
                        s->cj4.p, s->excl.p);
-    hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+    hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, (int *)nullptr, s->excl.p);
-    hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, s->ncj.p, s->cj4_start.p, s->cj4.p,
+    hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p,
                        nsp_max, (int *)nullptr, s->part_start.p, s->sci_a.p);
     S_TRY(hipGetLastError());
     const nbx_sci_t *sci_final = s->sci_a.p;

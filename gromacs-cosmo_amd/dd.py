@@ -52,6 +52,15 @@ class Domain:
     send_slots: np.ndarray     # grid slots of the home atoms the lower neighbour imports
     send_zshift: float         # added to their z on the way (periodic wrap at the bottom rank)
     halo_slots: np.ndarray     # grid slots the imported atoms occupy here
+    # what the device search needs to redo the gridding and both lists (nbnxn_hip_put_on_grid_zones)
+    zones: list = None         # [(corner0, corner1, a0, n)], home zone first
+    x_all: np.ndarray = None   # caller order: home atoms, then the imported ones
+    type_all: np.ndarray = None
+    q_all: np.ndarray = None
+    excl_index: np.ndarray = None
+    excl_a: np.ndarray = None
+    rlist: float = 0.0
+    min_ci_balanced: int = 0
 
     @property
     def pair_slots(self):
@@ -131,9 +140,11 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     # grids: zone 0 = home slab, zone 1 = the rlist-thick layer above it
     host = NbnxnHost(box, pbc_shift_dim=(1, 1, 0))
     z0 = rank * lz
-    host.put_on_grid(0, (0.0, 0.0, z0), (box[0], box[1], z0 + lz), 0, x_home)
+    zones = [((0.0, 0.0, z0), (float(box[0]), float(box[1]), z0 + lz), 0, nhome)]
+    host.put_on_grid(0, zones[0][0], zones[0][1], 0, x_home)
     if nhalo > 0:
-        host.put_on_grid(1, (0.0, 0.0, z0 + lz), (box[0], box[1], z0 + lz + ip.rlist), nhome, x_halo)
+        zones.append(((0.0, 0.0, z0 + lz), (float(box[0]), float(box[1]), z0 + lz + ip.rlist), nhome, nhalo))
+        host.put_on_grid(1, zones[1][0], zones[1][1], nhome, x_halo)
     ids_all = np.concatenate([home_ids, halo_ids])
     x_all = np.concatenate([x_home, x_halo]).astype(np.float32)
     ntype = glob.ntype + 1
@@ -163,7 +174,9 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
                   shift_vec=host.shift_vec(), pl_local=pl_local, pl_nonlocal=pl_nonlocal,
                   npad=len(xq), npad_local=host.natoms_padded_local,
                   send_slots=cell[down_sel].astype(np.int64), send_zshift=send_zshift,
-                  halo_slots=cell[nhome:nhome + nhalo].astype(np.int64))
+                  halo_slots=cell[nhome:nhome + nhalo].astype(np.int64),
+                  zones=zones, x_all=x_all, type_all=glob.type[ids_all].astype(np.int32), q_all=glob.q[ids_all].astype(np.float32),
+                  excl_index=excl_index, excl_a=excl_a, rlist=float(ip.rlist), min_ci_balanced=int(min_ci_balanced))
 
 
 class HaloExchange:
@@ -248,7 +261,7 @@ class _DevArray:
 class SlabRun:
     """Weak-scaling workload of bench.py: water_box(tx, ty, tz * world) cut into `world` z slabs."""
 
-    def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None):
+    def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None, device_search=True):
         from . import gpu
         self.flags = flags
         self.dev = torch.device("cuda", local_rank)
@@ -258,12 +271,25 @@ class SlabRun:
         mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced
         self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb)
         nb.init_const(ip, dom.ntype, dom.nbfp)
-        nb.init_atomdata(dom.npad, dom.npad_local, dom.ntype, dom.type)
-        nb.upload_shiftvec(dom.shift_vec)
-        nb.init_pairlist(dom.pl_local, abi.LOCAL)
-        nb.init_pairlist(dom.pl_nonlocal, abi.NONLOCAL)
-        assert nb.verify_pairlist(dom.pl_local, abi.LOCAL) == 0
-        assert nb.verify_pairlist(dom.pl_nonlocal, abi.NONLOCAL) == 0
+        if device_search:
+            # grids and both lists made on the device; the host-side builder's results, which the
+            # halo bookkeeping above came from, double as the check that both see the same grid
+            npad = nb.put_on_grid_zones(dom.box, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=(1, 1, 0))
+            assert npad == dom.npad
+            nb.make_pairlist(dom.rlist, dom.excl_index, dom.excl_a, dom.min_ci_balanced, iloc=abi.LOCAL)
+            if len(dom.zones) > 1:
+                nb.make_pairlist(dom.rlist, None, None, dom.min_ci_balanced, iloc=abi.NONLOCAL)
+            for iloc, pl in ((abi.LOCAL, dom.pl_local), (abi.NONLOCAL, dom.pl_nonlocal))[:len(dom.zones)]:
+                got = nb.download_pairlist(iloc)
+                assert (got.nsci, got.ncj4, got.nexcl, got.nci_tot) == (pl.nsci, pl.ncj4, pl.nexcl, pl.nci_tot)
+                assert np.array_equal(got.sci, pl.sci)
+        else:
+            nb.init_atomdata(dom.npad, dom.npad_local, dom.ntype, dom.type)
+            nb.upload_shiftvec(dom.shift_vec)
+            nb.init_pairlist(dom.pl_local, abi.LOCAL)
+            nb.init_pairlist(dom.pl_nonlocal, abi.NONLOCAL)
+            assert nb.verify_pairlist(dom.pl_local, abi.LOCAL) == 0
+            assert nb.verify_pairlist(dom.pl_nonlocal, abi.NONLOCAL) == 0
         # first pass the reference way: host xq in, forces out, both lists pruned, streams drained
         self.f_first, self.e_first = nb.compute_both(dom.xq, flags)
         d_xq, _, _ = nb.device_buffers()

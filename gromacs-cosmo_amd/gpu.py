@@ -101,6 +101,7 @@ def load():
     lib.nbnxn_hip_download_coulomb_tab.argtypes = [vp, vp, ci, C.POINTER(ci), C.POINTER(cf)]
     lib.nbnxn_hip_launch_kernel_pruneonly.argtypes = [vp, ci, cf, ci]
     lib.nbnxn_hip_put_on_grid.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, cf]
+    lib.nbnxn_hip_put_on_grid_zones.argtypes = [vp, vp, vp, ci, C.POINTER(abi.GridZone), ci, vp, ci, vp, vp]
     lib.nbnxn_hip_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci]
     lib.nbnxn_hip_forget_exclusions.argtypes = [vp]
     lib.nbnxn_hip_download_grid.argtypes = [vp] + [vp] * 8
@@ -200,6 +201,32 @@ class NbnxnHip:
         assert type_ is None or (len(type_) == n and len(q) == n)
         self._chk(self.lib.nbnxn_hip_put_on_grid(self.h, abi.ptr(box), abi.ptr(pbc), n, xp, on_dev, abi.ptr(type_), abi.ptr(q),
                                                  atom_density))
+        dims = np.zeros(4, dtype=np.int32)
+        self._chk(self.lib.nbnxn_hip_download_grid(self.h, abi.ptr(dims), None, None, None, None, None, None, None))
+        self.natoms = int(dims[3])
+        self.natoms_real = n
+        return self.natoms
+
+    def put_on_grid_zones(self, box, zones, x, type_, q, pbc_shift_dim=None):
+        """zones: list of (corner0, corner1, a0, n) -- home zone first, then the halo zones; x / type_ / q hold all
+        their atoms in that order.  Returns (padded atoms of all zones, padded atoms of the home zone)."""
+        box = np.ascontiguousarray(box, dtype=np.float32)
+        if type_ is not None:
+            type_ = np.ascontiguousarray(type_, dtype=np.int32)
+            q = np.ascontiguousarray(q, dtype=np.float32)
+        pbc = None if pbc_shift_dim is None else np.ascontiguousarray(pbc_shift_dim, dtype=np.int32)
+        zs = (abi.GridZone * len(zones))()
+        for k, (c0, c1, a0, n) in enumerate(zones):
+            zs[k].corner0[:] = [float(v) for v in c0]
+            zs[k].corner1[:] = [float(v) for v in c1]
+            zs[k].a0, zs[k].n, zs[k].atom_density = int(a0), int(n), 0.0
+        if hasattr(x, "__cuda_array_interface__"):
+            xp, on_dev, n = C.c_void_p(x.__cuda_array_interface__["data"][0]), 1, x.__cuda_array_interface__["shape"][0]
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            xp, on_dev, n = abi.ptr(x), 0, len(x)
+        self._chk(self.lib.nbnxn_hip_put_on_grid_zones(self.h, abi.ptr(box), abi.ptr(pbc), len(zones), zs, n, xp, on_dev,
+                                                       abi.ptr(type_), abi.ptr(q)))
         dims = np.zeros(4, dtype=np.int32)
         self._chk(self.lib.nbnxn_hip_download_grid(self.h, abi.ptr(dims), None, None, None, None, None, None, None))
         self.natoms = int(dims[3])

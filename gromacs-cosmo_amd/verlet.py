@@ -2,8 +2,8 @@
 (mdlib/sim_util.c:907-1530), with everything resident on the device:
 
   search steps (every nstlist):  nbnxn_put_on_grid + nbnxn_atomdata_set + nbnxn_cuda_init_atomdata
-                                 (:982-1007)            -> nbnxn_hip_put_on_grid
-                                 nbnxn_make_pairlist + nbnxn_cuda_init_pairlist (:1022-1034)
+                                 (:967-1007)            -> nbnxn_hip_put_on_grid
+                                 nbnxn_make_pairlist + nbnxn_cuda_init_pairlist (:1021-1034)
                                                         -> nbnxn_hip_make_pairlist
   other steps:                   nbnxn_atomdata_copy_x_to_nbat_x (:1044) -> nbnxn_hip_copy_x_to_xq
   every step:                    nbnxn_cuda_clear_outputs (:1486), do_nb_verlet (:622),

@@ -443,10 +443,10 @@ int nbnxn_hip_get_device_buffers(nbnxn_hip_ptr_t nb, void **d_xq, void **d_f, vo
 int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, int *stride);
 
 /* ------------------------------------------------------------------------------------
- * Pair search on the device (home zone, local list).  The two calls stand where the
- * reference's host code has nbnxn_put_on_grid (nbnxn_search.c:1777, called at sim_util.c:982)
+ * Pair search on the device.  The two calls stand where the
+ * reference's host code has nbnxn_put_on_grid (nbnxn_search.c:1777, called at sim_util.c:967)
  * + nbnxn_atomdata_set (nbnxn_atomdata.c:1094) + nbnxn_cuda_init_atomdata
- * (nbnxn_cuda_data_mgmt.h:81), and nbnxn_make_pairlist (nbnxn_search.c:5583, sim_util.c:1022)
+ * (nbnxn_cuda_data_mgmt.h:81), and nbnxn_make_pairlist (nbnxn_search.c:5583, sim_util.c:1021)
  * + nbnxn_cuda_init_pairlist (nbnxn_cuda_data_mgmt.h:75): atoms and list never visit the host.
  * ---------------------------------------------------------------------------------- */
 
@@ -461,16 +461,33 @@ int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, in
 int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
                           int x_on_device, const int *type, const float *q, float atom_density);
 
+/* The same for a domain with halo zones, as nbnxn_put_on_grid is called once per zone
+ * (sim_util.c:967 for the home zone, :978 nbnxn_put_on_grid_nonlocal for the others):
+ * zone 0 = home, zones 1.. = the halo zones in the decomposition's order, each with its corners,
+ * its atom range [a0, a0 + n) of x / type / q (home atoms first, then the communicated ones, as in
+ * the reference's state arrays) and its atom density (<= 0: n / zone volume).  The home zone's
+ * padded atoms come first in the grid-ordered arrays (they are the "local" range of
+ * nbnxn_hip_launch_kernel / _cpyback). */
+typedef struct {
+    float corner0[3], corner1[3];
+    int   a0, n;
+    float atom_density;
+} nbx_grid_zone_t;
+int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int nzones,
+                                const nbx_grid_zone_t *zones, int natoms, const float *x, int x_on_device, const int *type,
+                                const float *q);
+
 /* Builds the local list for the atoms gridded by nbnxn_hip_put_on_grid and installs it as
  * nbnxn_hip_init_pairlist would (its first kernel prunes it).  excl_index [natoms+1] / excl_a:
  * topology exclusions in caller atom numbering (t_blocka index / a); NULL = those of the last call
  * that passed them (none if there was no such call: use nbnxn_hip_forget_exclusions to drop them);
- * min_ci_balanced as for nbnxn_make_pairlist (nbnxn_hip_min_ci_balanced()).  iloc must be
- * NBX_LOCAL: halo zones stay with the host-side builder. */
+ * min_ci_balanced as for nbnxn_make_pairlist (nbnxn_hip_min_ci_balanced()).  iloc NBX_LOCAL: the
+ * home zone against itself; NBX_NONLOCAL: the home zone against the halo zones given to
+ * nbnxn_hip_put_on_grid_zones (nbnxn_search.c:5652-5699). */
 int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced);
 int nbnxn_hip_forget_exclusions(nbnxn_hip_ptr_t nb);
 
-/* Verification aids: the device grid (dims = {ncx, ncy, number of super-cells, padded atoms};
+/* Verification aids: the device grid (dims = {ncx, ncy of the home zone, super-cells and padded atoms of all zones};
  * a [padded], cell [natoms], bb [clusters][6] = lo xyz, hi xyz, bbcz [super-cells][2],
  * nsubc [super-cells], xq [padded][4], type [padded]; any pointer may be NULL) and the list
  * installed for iloc (counts = {nsci, ncj4, nexcl, nci_tot}; call once with NULL arrays for the sizes). */

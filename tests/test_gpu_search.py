@@ -157,7 +157,7 @@ def test_device_search_refusals(nb):
     nb.init_const(ip, s.ntype + 1, s.nbfp())
     nb.put_on_grid(s.box, s.x, s.type, s.q)
     with pytest.raises(RuntimeError):
-        nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0, iloc=abi.NONLOCAL)     # halo zones: host builder
+        nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0, iloc=abi.NONLOCAL)     # no halo zone on the grid
     with pytest.raises(RuntimeError):
         nb.make_pairlist(1.0, s.excl_index, s.excl_a, 0)                             # box 1.86 < 2 rlist
     with pytest.raises(RuntimeError):
@@ -274,3 +274,83 @@ def test_verlet_loop_with_dynamic_pruning(nb):
         p.host.add_f(np.asarray(o["f"], dtype=np.float32), fo)
         assert relrms(fd.cpu().numpy(), fo) < FORCE_RTOL, step
         x = x + vel
+
+
+def _slab_domain(glob, rank, world, rlist):
+    """the arrays dd.build_domain would hand to the grid for rank `rank` of `world` z-slabs (no messages needed here:
+    every rank of a test holds the global system)"""
+    box = np.asarray(glob.box, dtype=np.float32)
+    lz = float(box[2]) / world
+    owner = np.clip(np.floor(glob.x[:, 2].astype(np.float64) / lz).astype(np.int64), 0, world - 1)
+    home = np.nonzero(owner == rank)[0]
+    up = (rank + 1) % world
+    cand = np.nonzero(owner == up)[0]
+    zrel = glob.x[cand, 2] - np.float32(up * lz)
+    halo = cand[zrel < rlist]
+    x_halo = glob.x[halo].copy()
+    if up == 0:
+        x_halo[:, 2] += box[2]                       # across the periodic wrap
+    ids = np.concatenate([home, halo])
+    x_all = np.concatenate([glob.x[home], x_halo]).astype(np.float32)
+    z0 = rank * lz
+    zones = [((0.0, 0.0, z0), (box[0], box[1], z0 + lz), 0, len(home)),
+             ((0.0, 0.0, z0 + lz), (box[0], box[1], z0 + lz + rlist), len(home), len(halo))]
+    # topology exclusions in local numbering; partners that are not on this rank drop out
+    g2l = np.full(glob.natoms, -1, dtype=np.int64)
+    g2l[ids] = np.arange(len(ids))
+    ei, ea = [0], []
+    for a in ids:
+        part = g2l[glob.excl_a[glob.excl_index[a]:glob.excl_index[a + 1]]]
+        ea.extend(int(v) for v in part if v >= 0)
+        ei.append(len(ea))
+    return box, ids, x_all, zones, np.array(ei, dtype=np.int32), np.array(ea, dtype=np.int32)
+
+
+@pytest.mark.parametrize("kind,rank", [("water", 0), ("water", 1), ("chains", 1)])
+def test_device_search_with_a_halo_zone(nb, kind, rank):
+    """home zone + one halo zone (a z-slab decomposition's rank, the upper one wrapping around the box): both grids,
+    the local and the non-local list equal to the host builder's; forces of both kernels against the oracle"""
+    if kind == "water":
+        glob, ip = g.system.water_box(2, 2, 4, model="spce"), g.system.ewald(0.9)
+    else:
+        glob, ip = g.system.lj_chain_mixture(6000, ntype=8, seed=21), g.system.reaction_field(0.9, rlist=1.0)
+    box, ids, x_all, zones, ei, ea = _slab_domain(glob, rank, 2, ip.rlist)
+    mcb = 150
+    h = g.host.NbnxnHost(box, (1, 1, 0))
+    for zi, (c0, c1, a0, n) in enumerate(zones):
+        h.put_on_grid(zi, c0, c1, a0, x_all[a0:a0 + n])
+    ntype = glob.ntype + 1
+    xq, typ = h.set_atomdata(ntype, glob.type[ids], glob.q[ids])
+    h.copy_x_to_xq(x_all, xq)
+    pl_l = h.make_pairlist(abi.LOCAL, ip.rlist, xq, ei, ea, mcb)
+    pl_n = h.make_pairlist(abi.NONLOCAL, ip.rlist, xq, ei, ea, mcb)
+    assert pl_n.nsci > 0
+
+    nb.init_const(ip, ntype, glob.nbfp())
+    nb.forget_exclusions()
+    npad = nb.put_on_grid_zones(box, zones, x_all, glob.type[ids], glob.q[ids], pbc_shift_dim=(1, 1, 0))
+    assert npad == len(xq)
+    grid = nb.download_grid()
+    assert np.array_equal(grid["a"], h.atom_order()) and np.array_equal(grid["cell"], h.cell_index())
+    assert np.array_equal(grid["xq"].view(np.uint32), xq.view(np.uint32)) and np.array_equal(grid["type"], typ)
+    nb.make_pairlist(ip.rlist, ei, ea, mcb, iloc=abi.LOCAL)
+    nb.make_pairlist(ip.rlist, None, None, mcb, iloc=abi.NONLOCAL)
+    _assert_same_list(nb.download_pairlist(abi.LOCAL), pl_l)
+    _assert_same_list(nb.download_pairlist(abi.NONLOCAL), pl_n)
+    # both kernels on the device-built lists (on this one-stream handle they simply run in order)
+    o_l = O.kernel_gpu_list(xq, typ, ntype, glob.nbfp(), h.shift_vec(), pl_l, ip)
+    o_n = O.kernel_gpu_list(xq, typ, ntype, glob.nbfp(), h.shift_vec(), pl_n, ip)
+    f = np.zeros((npad, 3), dtype=np.float32)
+    nb.clear_outputs(abi.FORCE_VIRIAL)
+    nb.launch_kernel_resident(abi.FORCE_VIRIAL, abi.LOCAL)
+    nb.launch_kernel_resident(abi.FORCE_VIRIAL, abi.NONLOCAL)
+    nb.launch_cpyback(f, abi.FORCE_VIRIAL, abi.NONLOCAL)
+    nb.launch_cpyback(f, abi.FORCE_VIRIAL, abi.LOCAL)
+    nb.wait_gpu(abi.FORCE_VIRIAL, abi.NONLOCAL)
+    e_lj, e_el = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    fsh = np.zeros((abi.SHIFTS, 3), dtype=np.float32)
+    nb.wait_gpu(abi.FORCE_VIRIAL, abi.LOCAL, e_lj, e_el, fsh)
+    fo = np.asarray(o_l["f"]) + np.asarray(o_n["f"])
+    assert relrms(f, fo) < FORCE_RTOL
+    assert abs(e_lj[0] - (o_l["Vvdw"] + o_n["Vvdw"])) < ENERGY_RTOL * abs(o_l["Vvdw"] + o_n["Vvdw"])
+    assert abs(e_el[0] - (o_l["Vc"] + o_n["Vc"])) < ENERGY_RTOL * abs(o_l["Vc"] + o_n["Vc"])
