@@ -164,8 +164,12 @@ __device__ __forceinline__ float wave_sum(float v)
 
 constexpr int MAX_LDS_TYPES = NBX_KERNEL_MAX_LDS_TYPES;
 
-// bytes per type pair in the LDS parameter table: {c6, c12} or, for LJ-PME, {c6, c12, c6grid, -}
-constexpr int lds_entry_bytes(int vmod) { return vmod == 3 ? 16 : 8; }
+// A third per-type-pair value rides with {c6, c12} in two flavours: the grid C6 of LJ-PME, and, for the plain
+// cut-off energy kernels, 12 x the potential-shift term c12 rep_cpot / 12 - c6 disp_cpot / 6, which would
+// otherwise cost two instructions per PAIR (the LJ energy is then accumulated as 12 E and scaled once per wave).
+constexpr bool has_third(int vmod, bool ener) { return vmod == 3 || (vmod == 0 && ener); }
+// bytes per type pair in the LDS parameter table: {c6, c12} or {c6, c12, third, -}
+constexpr int lds_entry_bytes(int vmod, bool ener) { return has_third(vmod, ener) ? 16 : 8; }
 
 // j-forces are not sent to memory one cluster at a time: on CDNA the wave's loads, stores
 // and atomics retire in order through one counter (vmcnt), so a load issued after an atomic
@@ -239,9 +243,9 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
         t = and_mask(fmaf(qq, inv_r, lj6v) * inv_r2, m);
         if (ENER)
         {
-            // c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6, reusing lj6
-            const float shift = fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6);
-            elj = and_mask(fmaf(c.x * inv_r6, -1.0f / 12.0f, fmaf(lj6, 1.0f / 12.0f, shift)), m);
+            // 12 x [c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6] = lj6 - c6 r^-6 + c6g, with c6g = 12 x the
+            // shift term of the type pair (has_third); the 1/12 is applied to the wave's sum
+            elj = and_mask(fmaf(-c.x, inv_r6, lj6 + c6g), m);
         }
     }
     else if (VMOD == 3)
@@ -383,7 +387,8 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     if (!(imask & (0xffu << (JM * 8)))) { return; }
     float2 c[8];
     float  cg[8];
-    constexpr int TS = lds_entry_bytes(VMOD);
+    constexpr int  TS    = lds_entry_bytes(VMOD, ENER);
+    constexpr bool THIRD = has_third(VMOD, ENER);
     if (NBFP_LDS)
     {
         const char *row = reinterpret_cast<const char *>(s_nbfp) + s.t * (MAX_LDS_TYPES * TS);
@@ -392,7 +397,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
             c[i]  = *reinterpret_cast<const float2 *>(row + tb);
-            cg[i] = VMOD == 3 ? *reinterpret_cast<const float *>(row + tb + 8) : 0.0f;
+            cg[i] = THIRD ? *reinterpret_cast<const float *>(row + tb + 8) : 0.0f;
         }
     }
     else
@@ -404,6 +409,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
             c[i]  = a.nbfp[tb * a.ntype + s.t];
             cg[i] = VMOD == 3 ? a.c6grid[tb * a.ntype + s.t] : 0.0f;
             if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; cg[i] *= a.k.c6scale; }
+            if (VMOD == 0 && ENER) { cg[i] = 12.0f * fmaf(c[i].y, a.k.rep12, c[i].x * a.k.ndisp6); }
         }
     }
     float4 xj = s.x;
@@ -446,7 +452,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     __shared__ int    s_ti[64];
     __shared__ float  s_red[192];
     // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
-    constexpr int     TS = lds_entry_bytes(VMOD);
+    constexpr int     TS = lds_entry_bytes(VMOD, ENER);
     __shared__ __attribute__((aligned(16))) float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES * (TS / 8) : 1];
     constexpr int     FJ_CAP = 32;
     __shared__ float  s_fj[FJ_CAP * 24];
@@ -488,6 +494,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
                 char *entry = reinterpret_cast<char *>(s_nbfp) + (t_j * MAX_LDS_TYPES + t_i) * TS;
                 *reinterpret_cast<float2 *>(entry) = c;
                 if (VMOD == 3) { *reinterpret_cast<float *>(entry + 8) = a.c6grid[k] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
+                if (VMOD == 0 && ENER) { *reinterpret_cast<float *>(entry + 8) = 12.0f * fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6); }
             }
         }
     }
@@ -617,7 +624,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         const float sx = central ? 0.0f : wave_sum(rx);
         const float sy = central ? 0.0f : wave_sum(ry);
         const float sz = central ? 0.0f : wave_sum(rz);
-        E_lj = wave_sum(E_lj) * a.k.escale;
+        E_lj = wave_sum(E_lj) * a.k.escale * (VMOD == 0 ? 1.0f / 12.0f : 1.0f);
         E_el = wave_sum(E_el) * a.k.escale;
         // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
         float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
