@@ -140,7 +140,9 @@ __device__ __forceinline__ void pme_corr_fv(const float w, float &gf, float &gv)
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
-    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    // bound_ctrl = true: all lanes have a source for the permutations used here, and with it the compiler folds
+    // the move into one v_add_f32_dpp (without it row_half_mirror costs v_mov 0 + v_mov_dpp + v_add)
+    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
     return v + __builtin_bit_cast(float, m);
 }
 
@@ -396,8 +398,18 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         for (int i = 0; i < 8; i++)
         {
             const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
-            c[i]  = *reinterpret_cast<const float2 *>(row + tb);
-            cg[i] = THIRD ? *reinterpret_cast<const float *>(row + tb + 8) : 0.0f;
+            if (THIRD)
+            {
+                // 16-byte entries at 16-byte aligned addresses: one ds_read_b128 (the fourth word is padding)
+                const float4 v = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(row + tb, 16));
+                c[i]  = make_float2(v.x, v.y);
+                cg[i] = v.z;
+            }
+            else
+            {
+                c[i]  = *reinterpret_cast<const float2 *>(row + tb);
+                cg[i] = 0.0f;
+            }
         }
     }
     else
@@ -413,8 +425,8 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         }
     }
     float4 xj = s.x;
-    // Ewald: coordinates relative to the entry's origin (an exact subtraction), then scaled by beta
-    if (EL != NBX_EL_RF) { xj.x = (xj.x - ox) * a.k.xscale; xj.y = (xj.y - oy) * a.k.xscale; xj.z = (xj.z - oz) * a.k.xscale; }
+    // Ewald: scaled coordinates relative to the entry's origin, see the kernel
+    if (EL != NBX_EL_RF) { xj.x = fmaf(xj.x, a.k.xscale, ox); xj.y = fmaf(xj.y, a.k.xscale, oy); xj.z = fmaf(xj.z, a.k.xscale, oz); }
     float fjx = 0, fjy = 0, fjz = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -430,6 +442,9 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         }
     }
     fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
+    // keep the last reduction step out of the lane-masked store below: sunk in there, its cross-lane move
+    // can no longer be folded into the add (a DPP source lane must be active)
+    __asm__ volatile("" : "+v"(fjx), "+v"(fjy), "+v"(fjz));
     const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
     if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
     if (lane == 0) { s_fjc[nfj] = cj; }
@@ -502,15 +517,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 
     // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
     // their types are packed one per byte (LDS path: as byte offsets type*8 into a table row)
-    // Ewald: the origin of the scaled coordinates is the entry's first (shifted) i-atom; scaling
-    // the raw coordinates instead would round at ulp(beta |x|) and cost ~1e-5 of force accuracy
+    // Ewald: the scaled coordinates are x' = fma(x, beta, C) with C = -fl(beta * o), o the entry's first (shifted)
+    // i-atom.  The product is exact inside the fma and C is the SAME number for every i- and j-atom of the entry, so
+    // it cancels in x_i' - x_j': what is left is the rounding of two numbers of local magnitude (ulp(beta * 3 nm)),
+    // where scaling the raw coordinates would round at ulp(beta |x|) and cost ~1e-5 of force accuracy.
     float ox = 0, oy = 0, oz = 0;
     if (EL != NBX_EL_RF)
     {
         const float4 o = s_xqi[0];
-        ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
-        oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
-        oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
+        ox = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x))) * a.k.xscale);
+        oy = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y))) * a.k.xscale);
+        oz = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z))) * a.k.xscale);
     }
     float4   xi[8];
     unsigned tlo = 0, thi = 0;
@@ -521,7 +538,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         xi[i] = s_xqi[i * 8 + tidxi];
         if (EL != NBX_EL_RF)
         {
-            xi[i].x = (xi[i].x - ox) * a.k.xscale; xi[i].y = (xi[i].y - oy) * a.k.xscale; xi[i].z = (xi[i].z - oz) * a.k.xscale;
+            xi[i].x = fmaf(xi[i].x, a.k.xscale, ox); xi[i].y = fmaf(xi[i].y, a.k.xscale, oy); xi[i].z = fmaf(xi[i].z, a.k.xscale, oz);
         }
         const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? (unsigned)TS : 1u);
         if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
