@@ -373,8 +373,10 @@ __device__ __forceinline__ void load_jhdr(const nbx_kernel_view_t &a, int j4, in
 
 __device__ __forceinline__ void load_jslot(const nbx_kernel_view_t &a, int cj, int tidxj, nbx_jslot_t &s)
 {
-    s.x = a.xq[cj * 8 + tidxj];
-    s.t = a.type[cj * 8 + tidxj];
+    // unsigned index: base pointer in SGPRs + zero-extended 32-bit lane offset, no 64-bit address arithmetic per lane
+    const unsigned idx = (unsigned)(cj * 8 + tidxj);
+    s.x = a.xq[idx];
+    s.t = a.type[idx];
 }
 
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS, int JM>
