@@ -354,3 +354,19 @@ def test_device_search_with_a_halo_zone(nb, kind, rank):
     assert relrms(f, fo) < FORCE_RTOL
     assert abs(e_lj[0] - (o_l["Vvdw"] + o_n["Vvdw"])) < ENERGY_RTOL * abs(o_l["Vvdw"] + o_n["Vvdw"])
     assert abs(e_el[0] - (o_l["Vc"] + o_n["Vc"])) < ENERGY_RTOL * abs(o_l["Vc"] + o_n["Vc"])
+
+
+def test_device_search_at_config4_size(nb):
+    """1,533,168 atoms (BASELINE config 4): the device grid and list against the host builder's, whole arrays"""
+    s = g.system.water_box(13, 13, 14)
+    ip = g.system.reaction_field(1.0)
+    mcb = nb.min_ci_balanced()
+    p = g.workload.prepare(s, ip, mcb)
+    nb.forget_exclusions()
+    assert _device_search(nb, s, ip, mcb) == p.natoms
+    grid = nb.download_grid()
+    assert np.array_equal(grid["a"], p.host.atom_order()) and np.array_equal(grid["xq"].view(np.uint32), p.xq.view(np.uint32))
+    _assert_same_list(nb.download_pairlist(), p.pl)
+    # one force evaluation on it: Newton's third law over the whole box
+    f, _, _ = _forces_resident(nb, 0)
+    assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-3 * np.abs(f).max()
