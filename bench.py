@@ -49,6 +49,35 @@ def oracle_check(prep, ip, f_gpu, e_gpu):
             "pairs_in_cutoff_non_filler": int(o["counts"][2])}
 
 
+def large_system_leg(g, abi, ip, flags, model, flops_pair, peak_tflops, tiles=(13, 13, 14), nsteps=40):
+    """Secondary figure, outside the timed region of `value`: the same kernel on BASELINE config 4's
+    1.53 M atoms on this one GPU.  At 97 k atoms the list has to be split into ~15 k short entries to fill
+    256 CUs (nbnxn_hip_min_ci_balanced), and every entry pays its own prologue and i-force reduction; at
+    this size the entries are whole super-clusters, which shows what the pair loop itself reaches."""
+    import time
+    import torch
+    nb = g.gpu.NbnxnHip(0)
+    nb.set_timing(False)
+    nb.set_clear_in_kernel(True)
+    system = g.system.water_box(*tiles, model=model)
+    prep = g.workload.prepare(system, ip, nb.min_ci_balanced())
+    g.workload.upload(nb, prep, ip)
+    nb.compute(prep.xq, flags)                                   # prune step, coordinates now resident
+    for _ in range(5):
+        nb.clear_outputs(flags); nb.launch_kernel_resident(flags)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        nb.clear_outputs(flags); nb.launch_kernel_resident(flags)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / nsteps
+    nb.close()
+    return {"atoms": system.natoms, "pair_slots_per_step": prep.pair_slots, "nsci": prep.pl.nsci, "ms_per_step": ms,
+            "pairs_per_s": prep.pair_slots / (ms * 1e-3),
+            "roofline_frac": prep.pair_slots * flops_pair / (ms * 1e-3) / 1e12 / peak_tflops,
+            "note": "wall time per step (not kernel events), same flavour and flop count as the headline workload"}
+
+
 def verlet_loop_leg(g, abi, system, ip, flags, nstlist=10, nsteps=100):
     """Secondary figure, outside the timed region of `value`: the whole device-resident step of
     gromacs-cosmo_amd/verlet.py (search on the device every nstlist steps, x gather, kernel, f scatter
@@ -274,6 +303,7 @@ def main():
             out["parity"] = chk
             out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
+            out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

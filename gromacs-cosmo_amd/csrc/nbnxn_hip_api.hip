@@ -1295,6 +1295,14 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
     return 0;
 }
 
+int nbnxn_hip_set_progressive_balance(nbnxn_hip_ptr_t nb, int on)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->search) { nb->search = nbx_search_create(); }
+    nbx_search_set_progressive_balance(nb->search, on != 0);
+    return 0;
+}
+
 int nbnxn_hip_forget_exclusions(nbnxn_hip_ptr_t nb)
 {
     if (check_handle(nb)) { return 1; }

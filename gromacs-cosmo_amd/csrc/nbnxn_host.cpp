@@ -72,6 +72,7 @@ struct nbnxn_host {
     std::vector<int>  a;      // grid index -> atom
     std::vector<int>  cell;   // atom -> grid index
     List              lists[2];
+    bool              progressive = true;   // progressive balancing of split lists (progressive_nsp_max)
 };
 
 namespace {
@@ -602,6 +603,25 @@ void split_last_sci(PartList &pl, int nsp_max)
     }
 }
 
+// Progressive balancing.  The reference makes the entries of a list "progressively smaller, which improves load
+// balancing" (split_sci_entry with progBal, nbnxn_search.c:3928-3960) from a running entry count, which only a
+// sequential builder has.  The same end is reached here with a size class per (i super-cell, shift): three
+// quarters of the entries are split at 1.5x the average pair budget, an eighth at 0.75x and an eighth at 0.4x.
+// The number of entries stays about what min_ci_balanced asks for, while the entries the GPU runs last
+// (sort_sci orders by size) are well below the average, and with them the launch's tail, which lasts about one
+// entry.  Measured on an MI355X at 97 k atoms: +2-3 % over uniform entries, and no more dependence on how the
+// entry count happens to divide by the 4096 wave slots.  A function of (sci, shift) alone, so every builder and
+// every thread agrees on it (nbnxn_search.hip has the same function).
+inline int progressive_nsp_max(int nsp_max_av, int sci, int shift)
+{
+    if (nsp_max_av <= 0) { return nsp_max_av; }
+    unsigned h = (unsigned)sci * 2654435761u + (unsigned)shift * 40503u;
+    h ^= h >> 15;
+    const int   cls = (int)(h & 7u);
+    const float f   = cls < 6 ? 1.5f : (cls == 6 ? 0.75f : 0.4f);
+    return std::max(NSUBC * 4 / 2 + 1, (int)(nsp_max_av * f));
+}
+
 // get_nsubpair_max (nbnxn_search.c:4324-4408), local (single-grid) estimate
 int nsubpair_max(const Grid &g, float rlist, int min_ci_balanced, double frac_of_local)
 {
@@ -774,7 +794,11 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
                                 pl.cj_ind = ((pl.cj_ind + 3) >> 2) * 4;
                                 // drop a trailing cj4 that was opened but never used
                                 pl.cj4.resize(pl.cj_ind >> 2);
-                                if (nsp_max > 0) { split_last_sci(pl, nsp_max); }
+                                if (nsp_max > 0)
+                                {
+                                    const nbx_sci_t &le = pl.sci.back();
+                                    split_last_sci(pl, h->progressive ? progressive_nsp_max(nsp_max, le.sci, le.shift) : nsp_max);
+                                }
                             }
                             else
                             {
@@ -837,6 +861,13 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
     v.ncj4 = (int)L.cj4.size();   v.cj4 = L.cj4.data();   v.cj4_nalloc = (int)L.cj4.capacity();
     v.nexcl = (int)L.excl.size(); v.excl = L.excl.data(); v.excl_nalloc = (int)L.excl.capacity();
     v.nci_tot = L.nci_tot;
+    return 0;
+}
+
+int nbnxn_host_set_progressive_balance(nbnxn_host_ptr_t h, int on)
+{
+    if (!h) { return fail("null handle"); }
+    h->progressive = on != 0;
     return 0;
 }
 

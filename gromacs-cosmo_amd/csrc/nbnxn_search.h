@@ -11,6 +11,8 @@ struct nbx_search;
 
 nbx_search *nbx_search_create();
 void        nbx_search_destroy(nbx_search *s);
+// progressive balancing of split lists (default on), see progressive_nsp_max in nbnxn_host.cpp
+void        nbx_search_set_progressive_balance(nbx_search *s, bool on);
 // text of the last failure of a call that returned non-zero
 const char *nbx_search_error();
 

@@ -675,11 +675,22 @@ __global__ void k_excl_init(int n2, const int *__restrict__ need_excl, const int
     for (int t = 0; t < 32; t++) { excl[idx].pair[t] = 0xffffffffu; }
 }
 
+// progressive balancing: the host builder's progressive_nsp_max (nbnxn_host.cpp), the same function
+__device__ __forceinline__ int progressive_nsp_max(int nsp_max_av, int sci, int shift)
+{
+    if (nsp_max_av <= 0) { return nsp_max_av; }
+    unsigned h = (unsigned)sci * 2654435761u + (unsigned)shift * 40503u;
+    h ^= h >> 15;
+    const int   cls = (int)(h & 7u);
+    const float f   = cls < 6 ? 1.5f : (cls == 6 ? 0.75f : 0.4f);
+    return max(NSUBC * 4 / 2 + 1, (int)(nsp_max_av * f));
+}
+
 // split_sci_entry, one thread per entry.  WRITE = false: nparts[e]; WRITE = true: the entry's
 // nbnxn_sci_t parts at part_start[e].
 template <bool WRITE>
 __global__ void k_split(int nentries, int same, int njz, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
-                        const nbx_cj4_t *__restrict__ cj4, int nsp_max, int *__restrict__ nparts,
+                        const nbx_cj4_t *__restrict__ cj4, int nsp_max_av, int progressive, int *__restrict__ nparts,
                         const int *__restrict__ part_start, nbx_sci_t *__restrict__ sci_out)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -690,6 +701,7 @@ __global__ void k_split(int nentries, int same, int njz, const int *__restrict__
     const Entry en  = decode_entry(e, same, njz);
     const int sci   = en.sci;
     const int shift = shift_index(en.tx, en.ty, en.tz);
+    const int nsp_max = progressive ? progressive_nsp_max(nsp_max_av, sci, shift) : nsp_max_av;
     const int start = cj4_start[e], end = start + ((n + 3) >> 2);
     const int j4len = end - start;
     int       count = 0;
@@ -769,6 +781,7 @@ struct nbx_search {
     int   natoms = 0;      // atoms of all zones gridded so far
     int   nc     = 0;      // super-cells of all zones
     int   nsubc_tot0 = -1; // clusters with atoms in the home zone (read back when a list needs it)
+    bool  progressive = true;   // progressive balancing of split lists, as in the host builder
     Zone  zone[MAX_ZONES];
     // per super-cell / cluster / atom, all zones, global numbering
     Buf<int>      a, cell, nsubc, counters;
@@ -799,6 +812,8 @@ void nbx_search_destroy(nbx_search *s)
 }
 
 const char *nbx_search_error() { return g_err.c_str(); }
+
+void nbx_search_set_progressive_balance(nbx_search *s, bool on) { if (s) { s->progressive = on; } }
 
 int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[3], const int pbc_shift_dim[3],
                             const float corner0[3], const float corner1[3], int a0, int n, const float *d_x, float atom_density)
@@ -1010,7 +1025,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
     hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p,
-                       nsp_max, s->nparts.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
+                       nsp_max, s->progressive ? 1 : 0, s->nparts.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
     S_TRY(hipGetLastError());
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->need_excl.p, s->excl_rank.p, 2 * ncj4 + 1, st));
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->nparts.p, s->part_start.p, nent + 1, st));
@@ -1028,7 +1043,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, (int *)nullptr, s->excl.p);
     hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p,
-                       nsp_max, (int *)nullptr, s->part_start.p, s->sci_a.p);
+                       nsp_max, s->progressive ? 1 : 0, (int *)nullptr, s->part_start.p, s->sci_a.p);
     S_TRY(hipGetLastError());
     const nbx_sci_t *sci_final = s->sci_a.p;
     // sort_sci (:5517-5580): only when the groups outnumber the entries

@@ -104,6 +104,7 @@ def load():
     lib.nbnxn_hip_put_on_grid_zones.argtypes = [vp, vp, vp, ci, C.POINTER(abi.GridZone), ci, vp, ci, vp, vp]
     lib.nbnxn_hip_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci]
     lib.nbnxn_hip_forget_exclusions.argtypes = [vp]
+    lib.nbnxn_hip_set_progressive_balance.argtypes = [vp, ci]
     lib.nbnxn_hip_download_grid.argtypes = [vp] + [vp] * 8
     lib.nbnxn_hip_download_pairlist.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.nbnxn_hip_set_atom_order.argtypes = [vp, ci, vp, vp]
@@ -238,6 +239,9 @@ class NbnxnHip:
             excl_index = np.ascontiguousarray(excl_index, dtype=np.int32)
             excl_a = np.ascontiguousarray(excl_a, dtype=np.int32)
         self._chk(self.lib.nbnxn_hip_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a), min_ci_balanced))
+
+    def set_progressive_balance(self, on):
+        self._chk(self.lib.nbnxn_hip_set_progressive_balance(self.h, int(on)))
 
     def forget_exclusions(self):
         self._chk(self.lib.nbnxn_hip_forget_exclusions(self.h))

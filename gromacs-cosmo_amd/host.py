@@ -43,6 +43,7 @@ def _load():
     lib.nbnxn_host_pairlist.argtypes = [vp, ci]
     lib.nbnxn_host_pairlist.restype = C.POINTER(abi.Pairlist)
     lib.nbnxn_host_shift_vec.argtypes = [vp, vp]
+    lib.nbnxn_host_set_progressive_balance.argtypes = [vp, ci]
     _lib = lib
     return lib
 
@@ -163,6 +164,9 @@ class NbnxnHost:
     def pairlist_struct(self, iloc):
         """The nbnxn_pairlist_t-compatible view owned by the C++ side (valid until the next make_pairlist)."""
         return self.lib.nbnxn_host_pairlist(self.h, iloc)
+
+    def set_progressive_balance(self, on):
+        self._chk(self.lib.nbnxn_host_set_progressive_balance(self.h, int(on)))
 
     def shift_vec(self):
         sv = np.zeros((abi.SHIFTS, 3), dtype=np.float32)

@@ -486,6 +486,9 @@ int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const in
  * nbnxn_hip_put_on_grid_zones (nbnxn_search.c:5652-5699). */
 int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced);
 int nbnxn_hip_forget_exclusions(nbnxn_hip_ptr_t nb);
+/* Progressive balancing of the lists nbnxn_hip_make_pairlist splits (default on), the device builder's
+ * side of nbnxn_host_set_progressive_balance (include/nbnxn_host.h): same rule, same lists. */
+int nbnxn_hip_set_progressive_balance(nbnxn_hip_ptr_t nb, int on);
 
 /* Verification aids: the device grid (dims = {ncx, ncy of the home zone, super-cells and padded atoms of all zones};
  * a [padded], cell [natoms], bb [clusters][6] = lo xyz, hi xyz, bbcz [super-cells][2],

@@ -82,6 +82,13 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
                              const int *excl_index, const int *excl_a,
                              int min_ci_balanced, const float *xq);
 
+/* Progressive balancing of split lists (default on): entries get one of four pair budgets around the average
+ * that min_ci_balanced implies, by a hash of (i super-cell, shift), so that the smallest entries -- which the
+ * GPU runs last, the list being ordered by size -- are a third of the average (the reference's progBal,
+ * nbnxn_search.c:3928-3960, reaches the same end from a running entry count).  Off: every entry is split at
+ * the average budget. */
+int nbnxn_host_set_progressive_balance(nbnxn_host_ptr_t h, int on);
+
 /* the list built last for iloc, as an nbnxn_pairlist_t-compatible view (owned by h) */
 const nbx_pairlist_t *nbnxn_host_pairlist(nbnxn_host_ptr_t h, int iloc);
 

@@ -370,3 +370,28 @@ def test_device_search_at_config4_size(nb):
     # one force evaluation on it: Newton's third law over the whole box
     f, _, _ = _forces_resident(nb, 0)
     assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-3 * np.abs(f).max()
+
+
+def test_progressive_balance_switch(nb):
+    """both builders with progressive balancing off (every entry split at the average pair budget, the reference's
+    plain split_sci_entry) still agree, and the switch changes the split"""
+    s = g.system.water_box(2, 2, 2)
+    ip = g.system.reaction_field(0.9)
+    lists = []
+    for on in (False, True):
+        h = g.host.NbnxnHost(s.box)
+        h.set_progressive_balance(on)
+        h.put_on_grid(0, (0, 0, 0), s.box, 0, s.x)
+        xq, _ = h.set_atomdata(s.ntype + 1, s.type, s.q)
+        h.copy_x_to_xq(s.x, xq)
+        pl = h.make_pairlist(abi.LOCAL, ip.rlist, xq, s.excl_index, s.excl_a, 600)
+        nb.set_progressive_balance(on)
+        nb.forget_exclusions()
+        _device_search(nb, s, ip, 600)
+        _assert_same_list(nb.download_pairlist(), pl)
+        lists.append(pl)
+    nb.set_progressive_balance(True)
+    assert lists[0].ncj4 == lists[1].ncj4 and lists[0].nci_tot == lists[1].nci_tot      # the same pairs ...
+    len0 = np.sort(lists[0].sci["cj4_ind_end"] - lists[0].sci["cj4_ind_start"])
+    len1 = np.sort(lists[1].sci["cj4_ind_end"] - lists[1].sci["cj4_ind_start"])
+    assert len1.max() > len0.max() and np.median(len1[:len(len1) // 8]) <= np.median(len0[:len(len0) // 8])   # ... cut differently
