@@ -40,7 +40,111 @@ __global__ void __launch_bounds__(256) nbnxn_scatter_f(const int *__restrict__ c
     else { o[0] = fx; o[1] = fy; o[2] = fz; }
 }
 
+// Halo moves of a domain-decomposed step.  The reference packs and unpacks these
+// buffers on the CPU (dd_move_x, mdlib/domdec.c:651-758; dd_move_f, :761-875); here the
+// coordinates and forces never leave the device, so the same moves are four small kernels over
+// the grid-ordered arrays, one thread per halo atom.
+//   pack_x:   buf[i] = {xq[slot[i]].xyz + shift, q}     (the owner's side of dd_move_x)
+//   unpack_x: xq[slot[i]] = buf[i]                      (the importer's side)
+//   pack_f:   buf[i] = f[slot[i]]                       (the importer's side of dd_move_f)
+//   unpack_f: f[slot[i]] += buf[i], and with WRAP the sum of buf goes to one shift-force entry
+//             (what dd_move_f does for a pulse that crosses a periodic boundary, :837-851)
+__global__ void __launch_bounds__(256) nbnxn_halo_pack_x(const int *__restrict__ slot, int n, const float4 *__restrict__ xq,
+                                                         float sx, float sy, float sz, float4 *__restrict__ buf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) { return; }
+    float4 v = xq[slot[i]];
+    v.x += sx; v.y += sy; v.z += sz;
+    buf[i] = v;
+}
+
+__global__ void __launch_bounds__(256) nbnxn_halo_unpack_x(const int *__restrict__ slot, int n, const float4 *__restrict__ buf,
+                                                           float4 *__restrict__ xq)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) { return; }
+    xq[slot[i]] = buf[i];
+}
+
+__global__ void __launch_bounds__(256) nbnxn_halo_pack_f(const int *__restrict__ slot, int n, const float *__restrict__ f,
+                                                         float *__restrict__ buf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) { return; }
+    const int s = slot[i];
+    buf[3 * i + 0] = f[3 * s + 0];
+    buf[3 * i + 1] = f[3 * s + 1];
+    buf[3 * i + 2] = f[3 * s + 2];
+}
+
+// The force kernels may still be adding to f on the other stream: atomic adds (one address per
+// thread, no contention).  WRAP: block sum in double, one float atomic per block and component.
+template <bool WRAP>
+__global__ void __launch_bounds__(256) nbnxn_halo_unpack_f(const int *__restrict__ slot, int n, const float *__restrict__ buf,
+                                                           float *__restrict__ f, float *__restrict__ fshift_entry)
+{
+    const int i  = blockIdx.x * 256 + threadIdx.x;
+    float     fx = 0, fy = 0, fz = 0;
+    if (i < n)
+    {
+        const int s = slot[i];
+        fx = buf[3 * i + 0]; fy = buf[3 * i + 1]; fz = buf[3 * i + 2];
+        atomicAdd(f + 3 * s + 0, fx);
+        atomicAdd(f + 3 * s + 1, fy);
+        atomicAdd(f + 3 * s + 2, fz);
+    }
+    if (WRAP)
+    {
+        __shared__ double part[4][3];
+        double dx = fx, dy = fy, dz = fz;
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            dx += __shfl_down(dx, o);
+            dy += __shfl_down(dy, o);
+            dz += __shfl_down(dz, o);
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { part[w][0] = dx; part[w][1] = dy; part[w][2] = dz; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+        {
+            const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+            atomicAdd(fshift_entry + threadIdx.x, (float)t);
+        }
+    }
+}
+
 } // namespace
+
+hipError_t nbx_launch_halo_pack_x(const int *slot, int n, const float4 *xq, const float *shift, float4 *buf, hipStream_t stream)
+{
+    if (n <= 0) { return hipSuccess; }
+    hipLaunchKernelGGL(nbnxn_halo_pack_x, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, xq, shift[0], shift[1], shift[2], buf);
+    return hipGetLastError();
+}
+
+hipError_t nbx_launch_halo_unpack_x(const int *slot, int n, const float4 *buf, float4 *xq, hipStream_t stream)
+{
+    if (n <= 0) { return hipSuccess; }
+    hipLaunchKernelGGL(nbnxn_halo_unpack_x, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, buf, xq);
+    return hipGetLastError();
+}
+
+hipError_t nbx_launch_halo_pack_f(const int *slot, int n, const float *f, float *buf, hipStream_t stream)
+{
+    if (n <= 0) { return hipSuccess; }
+    hipLaunchKernelGGL(nbnxn_halo_pack_f, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, f, buf);
+    return hipGetLastError();
+}
+
+hipError_t nbx_launch_halo_unpack_f(const int *slot, int n, const float *buf, float *f, float *fshift_entry, hipStream_t stream)
+{
+    if (n <= 0) { return hipSuccess; }
+    if (fshift_entry) { hipLaunchKernelGGL(nbnxn_halo_unpack_f<true>, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, buf, f, fshift_entry); }
+    else { hipLaunchKernelGGL(nbnxn_halo_unpack_f<false>, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, buf, f, fshift_entry); }
+    return hipGetLastError();
+}
 
 hipError_t nbx_launch_gather_x(const int *a, const float *x, float4 *xq, int begin, int n, hipStream_t stream)
 {

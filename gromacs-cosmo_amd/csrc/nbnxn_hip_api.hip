@@ -95,6 +95,7 @@ struct nbnxn_hip {
     bool        two_streams = false;
     hipStream_t stream[2] = {nullptr, nullptr};
     hipEvent_t  misc_ops_done = nullptr, nonlocal_done = nullptr;
+    hipEvent_t  stream_mark[2] = {nullptr, nullptr};   // nbnxn_hip_stream_wait
     hipEvent_t  k_start[2] = {nullptr, nullptr}, k_stop[2] = {nullptr, nullptr};
     hipEvent_t  h2d_start[2] = {nullptr, nullptr}, h2d_stop[2] = {nullptr, nullptr};
     hipEvent_t  d2h_start[2] = {nullptr, nullptr}, d2h_stop[2] = {nullptr, nullptr};
@@ -658,6 +659,8 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
         HIP_TRY(hipStreamCreateWithPriority(&nb->stream[1], hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreateWithFlags(&nb->misc_ops_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&nb->stream_mark[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&nb->stream_mark[1], hipEventDisableTiming));
     }
     else
     {
@@ -902,6 +905,7 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     if (nb->two_streams)
     {
         (void)hipEventDestroy(nb->misc_ops_done); (void)hipEventDestroy(nb->nonlocal_done);
+        (void)hipEventDestroy(nb->stream_mark[0]); (void)hipEventDestroy(nb->stream_mark[1]);
         (void)hipStreamDestroy(nb->stream[1]);
     }
     (void)hipStreamDestroy(nb->stream[0]);
@@ -1399,6 +1403,65 @@ int nbnxn_hip_add_f(nbnxn_hip_ptr_t nb, float *f, int f_on_device, int a0, int n
     HIP_TRY(hipStreamSynchronize(st));
     float *o = f + (size_t)a0 * 3;
     for (size_t i = 0; i < (size_t)n * 3; i++) { o[i] += nb->h_fa[i]; }
+    return 0;
+}
+
+// ---- DD halo moves on the device ----
+
+namespace {
+int check_halo(nbnxn_hip *nb, const int *d_slots, int n, const void *d_buf, int iloc)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    if (n < 0 || n > nb->natoms) { return nbx_fail("halo of %d atoms on a grid of %d slots", n, nb->natoms); }
+    if (n > 0 && (!d_slots || !d_buf)) { return nbx_fail("null halo slot list or buffer"); }
+    if (!nb->xq.p || !nb->f.p) { return nbx_fail("halo move before the atom data exists"); }
+    return 0;
+}
+} // namespace
+
+int nbnxn_hip_halo_pack_x(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *shift, float *d_buf, int iloc)
+{
+    if (check_halo(nb, d_slots, n, d_buf, iloc)) { return 1; }
+    const float zero[3] = {0, 0, 0};
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(nbx_launch_halo_pack_x(d_slots, n, nb->xq.p, shift ? shift : zero, reinterpret_cast<float4 *>(d_buf), nb->stream[nb->two_streams ? iloc : 0]));
+    return 0;
+}
+
+int nbnxn_hip_halo_unpack_x(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *d_buf, int iloc)
+{
+    if (check_halo(nb, d_slots, n, d_buf, iloc)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(nbx_launch_halo_unpack_x(d_slots, n, reinterpret_cast<const float4 *>(d_buf), nb->xq.p, nb->stream[nb->two_streams ? iloc : 0]));
+    return 0;
+}
+
+int nbnxn_hip_halo_pack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, float *d_buf, int iloc)
+{
+    if (check_halo(nb, d_slots, n, d_buf, iloc)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(nbx_launch_halo_pack_f(d_slots, n, nb->f.p, d_buf, nb->stream[nb->two_streams ? iloc : 0]));
+    return 0;
+}
+
+int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *d_buf, int shift_index, int iloc)
+{
+    if (check_halo(nb, d_slots, n, d_buf, iloc)) { return 1; }
+    if (shift_index < -1 || shift_index >= 45) { return nbx_fail("shift index %d outside [-1, 45)", shift_index); }
+    HIP_TRY(hipSetDevice(nb->device));
+    // accumulation slot 0 of the output in use: {e_lj, e_el, fshift[45][3]}
+    float *entry = shift_index >= 0 ? nb->out + 2 + 3 * shift_index : nullptr;
+    HIP_TRY(nbx_launch_halo_unpack_f(d_slots, n, d_buf, nb->f.p, entry, nb->stream[nb->two_streams ? iloc : 0]));
+    return 0;
+}
+
+int nbnxn_hip_stream_wait(nbnxn_hip_ptr_t nb, int iloc_waits, int iloc_done)
+{
+    if (check_handle(nb) || check_loc(iloc_waits) || check_loc(iloc_done)) { return 1; }
+    if (!nb->two_streams || iloc_waits == iloc_done) { return 0; }   // one stream: already in order
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(hipEventRecord(nb->stream_mark[iloc_done], nb->stream[iloc_done]));
+    HIP_TRY(hipStreamWaitEvent(nb->stream[iloc_waits], nb->stream_mark[iloc_done], 0));
     return 0;
 }
 

@@ -93,5 +93,10 @@ hipError_t nbx_launch_prune(const float4 *xq, const float *shift_vec, const nbx_
 // nbnxn_atomdata.hip
 hipError_t nbx_launch_gather_x(const int *a, const float *x, float4 *xq, int begin, int n, hipStream_t stream);
 hipError_t nbx_launch_scatter_f(const int *cell, const float *fnb, float *f, int a0, int n, bool add, hipStream_t stream);
+// DD halo moves on the grid-ordered arrays (nbnxn_atomdata.hip)
+hipError_t nbx_launch_halo_pack_x(const int *slot, int n, const float4 *xq, const float *shift, float4 *buf, hipStream_t stream);
+hipError_t nbx_launch_halo_unpack_x(const int *slot, int n, const float4 *buf, float4 *xq, hipStream_t stream);
+hipError_t nbx_launch_halo_pack_f(const int *slot, int n, const float *f, float *buf, hipStream_t stream);
+hipError_t nbx_launch_halo_unpack_f(const int *slot, int n, const float *buf, float *f, float *fshift_entry, hipStream_t stream);
 
 #endif

@@ -111,6 +111,11 @@ def load():
     lib.nbnxn_hip_upload_xq_flat.argtypes = [vp, vp, ci]
     lib.nbnxn_hip_copy_x_to_xq.argtypes = [vp, vp, ci, ci]
     lib.nbnxn_hip_add_f.argtypes = [vp, vp, ci, ci, ci, ci]
+    lib.nbnxn_hip_halo_pack_x.argtypes = [vp, vp, ci, vp, vp, ci]
+    lib.nbnxn_hip_halo_unpack_x.argtypes = [vp, vp, ci, vp, ci]
+    lib.nbnxn_hip_halo_pack_f.argtypes = [vp, vp, ci, vp, ci]
+    lib.nbnxn_hip_halo_unpack_f.argtypes = [vp, vp, ci, vp, ci, ci]
+    lib.nbnxn_hip_stream_wait.argtypes = [vp, ci, ci]
     lib.nbnxn_hip_get_output_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
     lib.nbnxn_hip_set_timing.argtypes = [vp, ci]
     lib.nbnxn_hip_set_clear_in_kernel.argtypes = [vp, ci]
@@ -364,6 +369,23 @@ class NbnxnHip:
         else:
             assert f.dtype == np.float32 and f.shape == (self.natoms_real, 3) and f.flags.c_contiguous
             self._chk(self.lib.nbnxn_hip_add_f(self.h, abi.ptr(f), 0, a0, n, aloc))
+
+    # ---- DD halo moves on the device (device addresses as ints; slots int32) ----
+    def halo_pack_x(self, d_slots, n, shift, d_buf, iloc=abi.NONLOCAL):
+        sh = shift if shift is None or isinstance(shift, C.Array) else (C.c_float * 3)(*[float(v) for v in shift])
+        self._chk(self.lib.nbnxn_hip_halo_pack_x(self.h, d_slots, n, sh, d_buf, iloc))
+
+    def halo_unpack_x(self, d_slots, n, d_buf, iloc=abi.NONLOCAL):
+        self._chk(self.lib.nbnxn_hip_halo_unpack_x(self.h, d_slots, n, d_buf, iloc))
+
+    def halo_pack_f(self, d_slots, n, d_buf, iloc=abi.NONLOCAL):
+        self._chk(self.lib.nbnxn_hip_halo_pack_f(self.h, d_slots, n, d_buf, iloc))
+
+    def halo_unpack_f(self, d_slots, n, d_buf, shift_index=-1, iloc=abi.NONLOCAL):
+        self._chk(self.lib.nbnxn_hip_halo_unpack_f(self.h, d_slots, n, d_buf, shift_index, iloc))
+
+    def stream_wait(self, iloc_waits, iloc_done):
+        self._chk(self.lib.nbnxn_hip_stream_wait(self.h, iloc_waits, iloc_done))
 
     def set_clear_in_kernel(self, on):
         self._chk(self.lib.nbnxn_hip_set_clear_in_kernel(self.h, int(on)))

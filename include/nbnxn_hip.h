@@ -557,6 +557,31 @@ int nbnxn_hip_copy_x_to_xq(nbnxn_hip_ptr_t nb, const float *x, int x_on_device, 
  * on the stream of aloc.  Host f: returns when f is updated. */
 int nbnxn_hip_add_f(nbnxn_hip_ptr_t nb, float *f, int f_on_device, int a0, int n, int aloc);
 
+/* ------------------------------------------------------------------------------------
+ * Halo moves of a domain-decomposed step on the device.  The reference moves halo
+ * coordinates and forces through host buffers and MPI: dd_move_x (mdlib/domdec.c:651-758) copies
+ * the owner's atoms, plus the box shift of a pulse that crosses a periodic boundary (:685-706),
+ * into a send buffer; dd_move_f (:761-875) adds the forces that come back to the owner's atoms and,
+ * for such a pulse, to the shift force of that boundary as well (:837-851).  Here x and f live in
+ * HBM in grid order, so the buffers do too and a communication library (RCCL) takes them as they
+ * are.  d_slots are grid slots (device memory, n of them); d_buf is device memory; iloc names the
+ * stream the move is put on (one-stream handles: their only stream).
+ * ---------------------------------------------------------------------------------- */
+
+/* owner's side of dd_move_x: d_buf[i] = {xq[d_slots[i]].xyz + shift, q}; shift NULL = none */
+int nbnxn_hip_halo_pack_x(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *shift, float *d_buf, int iloc);
+/* importer's side: xq[d_slots[i]] = d_buf[i]  (float4 rows) */
+int nbnxn_hip_halo_unpack_x(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *d_buf, int iloc);
+/* importer's side of dd_move_f: d_buf[i] = f[d_slots[i]]  (3 floats per row) */
+int nbnxn_hip_halo_pack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, float *d_buf, int iloc);
+/* owner's side: f[d_slots[i]] += d_buf[i] (atomic, the force kernels may still be running);
+ * shift_index >= 0: the sum of d_buf is also added to that entry of the shift forces of the
+ * output in use (accumulation slot 0), shift_index -1: not. */
+int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *d_buf, int shift_index, int iloc);
+/* everything put on the stream of iloc_waits from here on runs after what the stream of
+ * iloc_done holds now (two pre-made events, no allocation); a no-op on one-stream handles */
+int nbnxn_hip_stream_wait(nbnxn_hip_ptr_t nb, int iloc_waits, int iloc_done);
+
 /* reads the (possibly pruned) cj4 array back from HBM; for tests of the prune flavour. */
 int nbnxn_hip_download_cj4(nbnxn_hip_ptr_t nb, int iloc, int ncj4, nbx_cj4_t *cj4);
 

@@ -351,6 +351,78 @@ def test_device_atomdata_moves_match_host_library(nb):
         nb.add_f(f_part, a0=s.natoms - 10, n=20)
 
 
+def test_halo_moves_on_the_device(nb):
+    """the pack / unpack kernels of the halo exchange (dd_move_x / dd_move_f,
+    domdec.c:651-875) against the same moves in numpy: copies and single float adds, so bit for bit;
+    the shift-force sum of a wrapped pulse within float rounding of its terms."""
+    import torch
+    from gromacs_cosmo_amd.dd import _DevArray
+    s = g.system.water_box(2, 2, 2, model="spc")
+    ip = g.system.reaction_field(0.9)
+    p = g.workload.prepare(s, ip, 0)
+    _upload(nb, p, ip)
+    nb.upload_xq(p.xq)
+    nb.clear_outputs(abi.FORCE_VIRIAL)
+    nb.wait_gpu(0)
+    d_xq, d_f, _ = nb.device_buffers()
+    d_out, nslots, stride = nb.output_slots()
+    xq_t = torch.as_tensor(_DevArray(d_xq, (p.natoms, 4)), device="cuda:0")
+    f_t = torch.as_tensor(_DevArray(d_f, (p.natoms, 3)), device="cuda:0")
+    out_t = torch.as_tensor(_DevArray(d_out, (nslots * stride,)), device="cuda:0")
+    rng = np.random.default_rng(5)
+    n = 777
+    slots = rng.permutation(p.natoms)[:n].astype(np.int32)
+    slots_t = torch.from_numpy(slots).cuda()
+    shift = np.array([0.5, -1.0, 2.25], dtype=np.float32)
+    for iloc in (abi.LOCAL, abi.NONLOCAL):
+        buf = torch.zeros((n, 4), device="cuda:0")
+        nb.halo_pack_x(slots_t.data_ptr(), n, shift, buf.data_ptr(), iloc)
+        torch.cuda.synchronize()
+        want = p.xq[slots].copy()
+        want[:, :3] += shift
+        assert np.array_equal(buf.cpu().numpy(), want)
+        nb.halo_pack_x(slots_t.data_ptr(), n, None, buf.data_ptr(), iloc)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), p.xq[slots])
+    new = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    nb.halo_unpack_x(slots_t.data_ptr(), n, torch.from_numpy(new).cuda().data_ptr())
+    torch.cuda.synchronize()
+    want = p.xq.copy()
+    want[slots] = new
+    assert np.array_equal(xq_t.cpu().numpy(), want)
+    f0 = rng.normal(0, 300, (p.natoms, 3)).astype(np.float32)
+    f_t.copy_(torch.from_numpy(f0))
+    fbuf = torch.zeros((n, 3), device="cuda:0")
+    nb.halo_pack_f(slots_t.data_ptr(), n, fbuf.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(fbuf.cpu().numpy(), f0[slots])
+    back = rng.normal(0, 300, (n, 3)).astype(np.float32)
+    back_t = torch.from_numpy(back).cuda()
+    nb.halo_unpack_f(slots_t.data_ptr(), n, back_t.data_ptr(), -1)
+    torch.cuda.synchronize()
+    want = f0.copy()
+    want[slots] += back
+    assert np.array_equal(f_t.cpu().numpy(), want)
+    assert float(out_t.abs().max()) == 0.0
+    nb.halo_unpack_f(slots_t.data_ptr(), n, back_t.data_ptr(), 17)
+    torch.cuda.synchronize()
+    want[slots] += back
+    assert np.array_equal(f_t.cpu().numpy(), want)
+    o = out_t.cpu().numpy()
+    got = o[2 + 3 * 17:5 + 3 * 17].astype(np.float64)
+    assert np.abs(got - back.astype(np.float64).sum(0)).max() < 1e-6 * np.abs(back).sum()
+    o[2 + 3 * 17:5 + 3 * 17] = 0
+    assert not o.any()
+    nb.halo_unpack_f(slots_t.data_ptr(), 0, 0, 17)        # an empty halo is fine
+    nb.stream_wait(abi.LOCAL, abi.NONLOCAL)
+    with pytest.raises(g.gpu.HipError):
+        nb.halo_pack_f(slots_t.data_ptr(), p.natoms + 1, fbuf.data_ptr())
+    with pytest.raises(g.gpu.HipError):
+        nb.halo_unpack_f(slots_t.data_ptr(), n, back_t.data_ptr(), 45)
+    with pytest.raises(g.gpu.HipError):
+        nb.halo_pack_x(0, n, None, buf.data_ptr())
+
+
 def test_twin_range_flavour_and_pme_loadbal_update(nb):
     """rvdw < rcoulomb (VDW_CUTOFF_CHECK flavours, nbnxn_cuda_kernel.cuh:405-441) against the oracle,
     reached both ways the reference reaches it: init_const with a twin-range interaction_const_t,

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 DEADLINE_S = 100
 
 
-def _worker(rank, world, port, model, ret):
+def _worker(rank, world, port, model, device_halo, ret):
     import datetime
     import faulthandler
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -36,13 +36,14 @@ def _worker(rank, world, port, model, ret):
     import gromacs_cosmo_amd as g
     from gromacs_cosmo_amd import abi, dd
     import oracle as O
+    from util import virial_from
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
                             timeout=datetime.timedelta(seconds=60))
     try:
         torch.cuda.set_device(0)
         ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
         tiles = (2, 2, 2)
-        run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300)
+        run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo)
         dom = run.dom
         # wreck the imported coordinates on the device: the step has to bring them back
         run.xq_t[run.halo.halo_slots, :3] = 1e6
@@ -56,8 +57,16 @@ def _worker(rank, world, port, model, ret):
         f_ref = np.zeros((glob.natoms, 3), dtype=np.float32)
         prep.host.add_f(np.asarray(o["f"], dtype=np.float32), f_ref)
         fr = f_ref[dom.home_ids]
+        # virial: home atoms' x (x) f summed over ranks, plus the shift-force term, which includes the forces
+        # that came back across the periodic wrap (dd_move_f, domdec.c:837-851)
+        xf_t = torch.from_numpy(glob.x[dom.home_ids].astype(np.float64).T @ f_home.astype(np.float64))
+        dist.all_reduce(xf_t)
+        vir_dd = -0.5 * (xf_t.numpy() + dom.shift_vec.astype(np.float64).T @ e[2:2 + 135].reshape(45, 3))
+        vir_ref = virial_from(np.concatenate([glob.x, np.zeros((glob.natoms, 1), np.float32)], 1), f_ref,
+                              prep.shift_vec, np.asarray(o["fshift"]))
         ret[rank] = dict(err=float(np.sqrt(((f_home - fr) ** 2).sum() / (fr ** 2).sum())),
-                         e_lj=float(e[0]), e_el=float(e[1]), e_lj_ref=float(o["Vvdw"]), e_el_ref=float(o["Vc"]))
+                         e_lj=float(e[0]), e_el=float(e[1]), e_lj_ref=float(o["Vvdw"]), e_el_ref=float(o["Vc"]),
+                         vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()))
     finally:
         dist.destroy_process_group()
         faulthandler.cancel_dump_traceback_later()
@@ -66,21 +75,72 @@ def _worker(rank, world, port, model, ret):
             os.remove(hang_log.name)
 
 
-@pytest.mark.parametrize("model", ["spc", "spce"])
-def test_slabrun_two_ranks_one_gpu(model):
+def _watch(ctx):
+    t0 = time.time()
+    while not ctx.join(timeout=2):
+        if time.time() - t0 > DEADLINE_S:
+            alive = [i for i, p in enumerate(ctx.processes) if p.is_alive()]
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            pytest.fail(f"ranks {alive} still running after {DEADLINE_S} s; their stacks are in gpurun_out/dd_hang_rank*.txt")
+
+
+@pytest.mark.parametrize("model,device_halo", [("spc", True), ("spce", True), ("spce", False)])
+def test_slabrun_two_ranks_one_gpu(model, device_halo):
     with mp.Manager() as m:
         ret = m.dict()
-        ctx = mp.spawn(_worker, args=(2, _free_port(), model, ret), nprocs=2, join=False)
-        t0 = time.time()
-        while not ctx.join(timeout=2):
-            if time.time() - t0 > DEADLINE_S:
-                alive = [i for i, p in enumerate(ctx.processes) if p.is_alive()]
-                for p in ctx.processes:
-                    if p.is_alive():
-                        p.kill()
-                pytest.fail(f"ranks {alive} still running after {DEADLINE_S} s; their stacks are in gpurun_out/dd_hang_rank*.txt")
+        ctx = mp.spawn(_worker, args=(2, _free_port(), model, device_halo, ret), nprocs=2, join=False)
+        _watch(ctx)
         res = [ret[r] for r in range(2)]
     for r in res:
         assert r["err"] < 1e-5, r
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
+        assert r["vir_err"] < 1e-5, r
+
+
+def _rccl_worker(rank, port, ret):
+    """one rank, the RCCL backend: the exchange and the slot reduction as bench.py --gpus N issues them,
+    to itself (RCCL needs one GPU per rank, so one rank is all a one-GPU box can give it)"""
+    import datetime
+    import faulthandler
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    hang_log = open(os.path.join(ROOT, "gpurun_out", "dd_hang_rccl.txt"), "w")
+    faulthandler.dump_traceback_later(DEADLINE_S - 20, file=hang_log, exit=False)
+    from gromacs_cosmo_amd import dd
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                            timeout=datetime.timedelta(seconds=60))
+    try:
+        side = torch.cuda.Stream()
+        ok = True
+        with torch.cuda.stream(side):
+            for n in (1000, 0, 37):
+                s = torch.randn((n, 4), device=dev)
+                r = torch.zeros((n, 4), device=dev)
+                dd._exchange(s, 0, r, 0)
+                ok = ok and bool((r == s).all())
+            ids = torch.arange(50, dtype=torch.int64, device=dev)
+            got = torch.zeros_like(ids)
+            dd._exchange(ids, 0, got, 0)
+            ok = ok and bool((got == ids).all())
+            out = torch.ones(1000, device=dev)
+            dd.reduce_slots(out)
+            ok = ok and bool((out == 1).all())
+        torch.cuda.synchronize()
+        ret["ok"] = ok
+    finally:
+        dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
+        hang_log.close()
+        if os.path.getsize(hang_log.name) == 0:
+            os.remove(hang_log.name)
+
+
+def test_exchange_over_rccl_single_rank():
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_rccl_worker, args=(_free_port(), ret), nprocs=1, join=False))
+        assert ret["ok"]
