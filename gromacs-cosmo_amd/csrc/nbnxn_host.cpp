@@ -66,8 +66,11 @@ struct List {
 } // namespace
 
 struct nbnxn_host {
-    float             box[3]      = {0, 0, 0};
-    int               shp[3]      = {1, 1, 1};
+    float             box[3]      = {0, 0, 0};   // the diagonal
+    // off-diagonal elements of a triclinic box (rows are box vectors, GROMACS layout: box[YY][XX],
+    // box[ZZ][XX], box[ZZ][YY]; the upper triangle is zero by check_box, gmxlib/pbc.c:135)
+    float             byx = 0, bzx = 0, bzy = 0;
+    int               shp[3]      = {1, 1, 1};   // which dimensions get periodic shifts (1) or none (0)
     std::vector<Grid> grids;
     std::vector<int>  a;      // grid index -> atom
     std::vector<int>  cell;   // atom -> grid index
@@ -117,12 +120,37 @@ void nbnxn_host_destroy(nbnxn_host_ptr_t h) { delete h; }
 int nbnxn_host_set_box(nbnxn_host_ptr_t h, const float box[3], const int pbc_shift_dim[3])
 {
     if (!h) { return fail("null handle"); }
+    const float m[9] = {box[0], 0, 0, 0, box[1], 0, 0, 0, box[2]};
+    return nbnxn_host_set_box_triclinic(h, m, pbc_shift_dim);
+}
+
+int nbnxn_host_set_box_triclinic(nbnxn_host_ptr_t h, const float box[9], const int pbc_shift_dim[3])
+{
+    if (!h) { return fail("null handle"); }
     for (int d = 0; d < 3; d++)
     {
-        if (!(box[d] > 0)) { return fail("box[%d] = %g must be > 0", d, box[d]); }
-        h->box[d] = box[d];
+        if (!(box[4 * d] > 0)) { return fail("box[%d][%d] = %g must be > 0", d, d, box[4 * d]); }
+    }
+    // check_box (gmxlib/pbc.c:121-156)
+    if (box[1] != 0 || box[2] != 0 || box[5] != 0)
+    {
+        return fail("Only triclinic boxes with the first vector parallel to the x-axis and the second vector in the xy-plane are supported.");
+    }
+    const float margin = 1.0010f;   // BOX_MARGIN, pbc.c:68
+    if (std::fabs(box[3]) > margin * 0.5f * box[0] || std::fabs(box[6]) > margin * 0.5f * box[0] || std::fabs(box[7]) > margin * 0.5f * box[4])
+    {
+        return fail("Triclinic box is too skewed.");
+    }
+    if ((box[3] != 0 && !(pbc_shift_dim[0] && pbc_shift_dim[1])) || ((box[6] != 0 || box[7] != 0) && !(pbc_shift_dim[0] && pbc_shift_dim[1] && pbc_shift_dim[2])))
+    {
+        return fail("a triclinic box vector needs periodic shifts in the dimensions it couples");
+    }
+    for (int d = 0; d < 3; d++)
+    {
+        h->box[d] = box[4 * d];
         h->shp[d] = pbc_shift_dim[d] ? 1 : 0;
     }
+    h->byx = box[3]; h->bzx = box[6]; h->bzy = box[7];
     h->grids.clear();
     h->a.clear();
     h->cell.clear();
@@ -390,8 +418,9 @@ int nbnxn_host_shift_vec(nbnxn_host_ptr_t h, float *sv)
         {
             for (int tx = -2; tx <= 2; tx++)
             {
-                sv[3 * is + 0] = tx * h->box[0];
-                sv[3 * is + 1] = ty * h->box[1];
+                // calc_shifts (gmxlib/pbc.c:1326-1349): k box[XX] + l box[YY] + m box[ZZ], in float
+                sv[3 * is + 0] = tx * h->box[0] + ty * h->byx + tz * h->bzx;
+                sv[3 * is + 1] = ty * h->box[1] + tz * h->bzy;
                 sv[3 * is + 2] = tz * h->box[2];
                 is++;
             }
@@ -660,6 +689,14 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
             return fail("box[%d] = %g is shorter than 2*rlist = %g: more than one periodic image in range", d, h->box[d], 2 * rlist);
         }
     }
+    // the second limit of max_cutoff2 (gmxlib/pbc.c:171-185): only single box vectors (two in x) are tried
+    if (h->shp[1] && h->shp[2] && h->box[1] - std::fabs(h->bzy) < rlist)
+    {
+        return fail("box[YY][YY] - |box[ZZ][YY]| = %g is shorter than rlist = %g", h->box[1] - std::fabs(h->bzy), rlist);
+    }
+    // shift range (nbnxn_search.c:4906-4927): a skewed box can need two box lengths in x
+    int shp[3] = {h->shp[0], h->shp[1], h->shp[2]};
+    if (shp[0] && h->box[0] - std::fabs(h->byx) - std::fabs(h->bzx) < rlist) { shp[0] = 2; }
     const Grid &gi  = h->grids[0];
     const float rl2 = rlist * rlist;
     const int   jz0 = (iloc == NBX_LOCAL) ? 0 : 1;
@@ -706,16 +743,17 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
                 const float bbx = 0.5f * (gi.sx + gj.sx) / 2, bby = 0.5f * (gi.sy + gj.sy) / 2;
                 // boundingbox_only_distance2 (:4721-4757)
                 const float rbb2 = sqr(std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby)));
-                for (int tz = -h->shp[2]; tz <= h->shp[2]; tz++)
+                for (int tz = -shp[2]; tz <= shp[2]; tz++)
                 {
-                    for (int ty = -h->shp[1]; ty <= h->shp[1]; ty++)
+                    for (int ty = -shp[1]; ty <= shp[1]; ty++)
                     {
-                        for (int tx = -h->shp[0]; tx <= h->shp[0]; tx++)
+                        for (int tx = -shp[0]; tx <= shp[0]; tx++)
                         {
                             const int shift = 5 * (3 * (tz + 1) + ty + 1) + tx + 2;   // XYZ2IS
                             // one-way lists: only backward shifts within one grid (:5091-5096)
                             if (same_grid && shift > NBX_CENTRAL) { continue; }
-                            const float sh[3] = { tx * h->box[0], ty * h->box[1], tz * h->box[2] };
+                            // shx, shy, shz (:5019, :5054, :5098)
+                            const float sh[3] = { tx * h->box[0] + ty * h->byx + tz * h->bzx, ty * h->box[1] + tz * h->bzy, tz * h->box[2] };
                             BB bS = bI;
                             for (int d = 0; d < 3; d++) { bS.lo[d] += sh[d]; bS.hi[d] += sh[d]; }
                             // j column range

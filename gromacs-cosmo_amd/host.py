@@ -27,6 +27,7 @@ def _load():
     lib.nbnxn_host_create.restype = vp
     lib.nbnxn_host_destroy.argtypes = [vp]
     lib.nbnxn_host_set_box.argtypes = [vp, fp, ip]
+    lib.nbnxn_host_set_box_triclinic.argtypes = [vp, fp, ip]
     lib.nbnxn_host_put_on_grid.argtypes = [vp, ci, fp, fp, ci, ci, vp, cf]
     lib.nbnxn_host_natoms_padded.argtypes = [vp]
     lib.nbnxn_host_natoms_padded_local.argtypes = [vp]
@@ -80,10 +81,17 @@ class NbnxnHost:
     def __init__(self, box, pbc_shift_dim=(1, 1, 1)):
         self.lib = _load()
         self.h = self.lib.nbnxn_host_create()
-        self.box = np.asarray(box, dtype=np.float32)
-        b = (C.c_float * 3)(*self.box)
+        # box: [3] rectangular, or the [3, 3] GROMACS matrix (rows are box vectors) of a triclinic cell
+        box = np.asarray(box, dtype=np.float32)
         p = (C.c_int * 3)(*[int(v) for v in pbc_shift_dim])
-        self._chk(self.lib.nbnxn_host_set_box(self.h, b, p))
+        if box.shape == (3, 3):
+            self.box_matrix = box.copy()
+            self.box = np.ascontiguousarray(np.diag(box))
+            self._chk(self.lib.nbnxn_host_set_box_triclinic(self.h, (C.c_float * 9)(*box.reshape(-1)), p))
+        else:
+            self.box = box
+            self.box_matrix = np.diag(box).astype(np.float32)
+            self._chk(self.lib.nbnxn_host_set_box(self.h, (C.c_float * 3)(*box), p))
         self.natoms = 0
 
     def __del__(self):

@@ -24,7 +24,7 @@ Q_SPCE = (-0.8476, 0.4238, 0.4238)
 class System:
     """Topology + coordinates in caller (molecule) order."""
     x: np.ndarray            # [n,3] float32, inside the box
-    box: np.ndarray          # [3]
+    box: np.ndarray          # [3] rectangular, or the [3, 3] GROMACS matrix (rows are box vectors) of a triclinic cell
     type: np.ndarray         # [n] int32, 0..ntype-1 (without the dummy type)
     q: np.ndarray            # [n] float32
     ntype: int               # number of real types; the list format adds one dummy type
@@ -37,6 +37,12 @@ class System:
     @property
     def natoms(self):
         return len(self.x)
+
+    @property
+    def box_diag(self):
+        """the brick the atoms live in: put_atoms_in_box leaves them in [0, box[d][d]) (gmxlib/pbc.c:1562)"""
+        b = np.asarray(self.box, dtype=np.float32)
+        return np.ascontiguousarray(np.diag(b)) if b.shape == (3, 3) else b
 
     def nbfp(self):
         """6*C6 / 12*C12 table including the zero dummy type: nbnxn_atomdata.c:561,611-617,636-638."""
@@ -259,10 +265,13 @@ def water_box(nx, ny, nz, model="spc"):
                   excl_index=excl_index, excl_a=excl_a, name=f"{model}216x{nx}x{ny}x{nz}")
 
 
-def lj_chain_mixture(natoms, ntype=8, seed=2026, density=100.0, chain_len=(12, 40)):
+def lj_chain_mixture(natoms, ntype=8, seed=2026, density=100.0, chain_len=(12, 40), skew=None):
     """Config-5-like synthetic system: an ntype-type LJ mixture of chain molecules with
     1-2 and 1-3 exclusions and partial charges, on a jittered lattice (no reference fixture
-    exists for it).  Exclusion-dense, mixed LJ types."""
+    exists for it).  Exclusion-dense, mixed LJ types.
+    skew = (kyx, kzx, kzy): a triclinic cell whose off-diagonal elements box[YY][XX], box[ZZ][XX],
+    box[ZZ][YY] are these multiples of the lattice spacing, so the lattice stays commensurate with its
+    periodic images and no two atoms come closer than in the rectangular cell."""
     rng = np.random.default_rng(seed)
     vol = natoms / density
     L = vol ** (1.0 / 3.0)
@@ -305,5 +314,8 @@ def lj_chain_mixture(natoms, ntype=8, seed=2026, density=100.0, chain_len=(12, 4
             ex_lists.append(np.arange(s0 + lo, s0 + hi + 1, dtype=np.int32))
     excl_index = np.concatenate([[0], np.cumsum([len(e_) for e_ in ex_lists])]).astype(np.int32)
     excl_a = np.concatenate(ex_lists).astype(np.int32)
+    if skew is not None:
+        box = np.diag(box).astype(np.float32)
+        box[1, 0], box[2, 0], box[2, 1] = skew[0] * a, skew[1] * a, skew[2] * a
     return System(x=x, box=box, type=type_, q=q.astype(np.float32), ntype=ntype, c6=c6, c12=c12,
-                  excl_index=excl_index, excl_a=excl_a, name=f"ljchain{natoms}")
+                  excl_index=excl_index, excl_a=excl_a, name=f"ljchain{natoms}" + ("" if skew is None else "_tric"))

@@ -27,7 +27,7 @@ class Prepared:
 
 def prepare(system, ip, min_ci_balanced=0):
     h = NbnxnHost(system.box)
-    h.put_on_grid(0, (0.0, 0.0, 0.0), system.box, 0, system.x)
+    h.put_on_grid(0, (0.0, 0.0, 0.0), system.box_diag, 0, system.x)
     ntype = system.ntype + 1
     xq, typ = h.set_atomdata(ntype, system.type, system.q)
     h.copy_x_to_xq(system.x, xq)

@@ -37,6 +37,12 @@ void             nbnxn_host_destroy(nbnxn_host_ptr_t h);
  * pair search; a dimension that is domain-decomposed gets none (nbnxn_search.c:4906-4927). */
 int nbnxn_host_set_box(nbnxn_host_ptr_t h, const float box[3], const int pbc_shift_dim[3]);
 
+/* The same for a triclinic box: box[9] is the GROMACS matrix, rows are box vectors, lower triangular
+ * and within the skew limits of check_box (gmxlib/pbc.c:121-156).  Atoms are expected in the
+ * rectangular brick [0, box[d][d]) that put_atoms_in_box leaves them in (pbc.c:1562); the
+ * search then visits up to 5 x 3 x 3 shift vectors (nbnxn_search.c:4906-4927, :5017-5098). */
+int nbnxn_host_set_box_triclinic(nbnxn_host_ptr_t h, const float box[9], const int pbc_shift_dim[3]);
+
 /* nbnxn_put_on_grid for zone `zone` (0 = home, >0 = halo zones, in order).  x is [n*3]
  * for the atoms a0..a0+n-1 of the caller's local numbering (home atoms first, halo atoms
  * after).  corner0/corner1 bound the zone.  atom_density <= 0: computed from n and the

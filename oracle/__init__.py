@@ -188,7 +188,9 @@ def brute_force(x, q, type_, ntype, nbfp, box, excl_index, excl_a, ip, calc_ener
     type_ = np.ascontiguousarray(type_, dtype=np.int32)
     nbfp = np.ascontiguousarray(nbfp, dtype=np.float32)
     box = np.ascontiguousarray(box, dtype=np.float32)
-    lib().oracle_brute_force(C.c_int(n), _p(x), _p(q), _p(type_), C.c_int(ntype), _p(nbfp), _p(box),
+    # a [3] box is rectangular, a [3, 3] box the GROMACS matrix (rows are box vectors)
+    fn = lib().oracle_brute_force_tric if box.size == 9 else lib().oracle_brute_force
+    fn(C.c_int(n), _p(x), _p(q), _p(type_), C.c_int(ntype), _p(nbfp), _p(box),
                              _p(excl_index), _p(excl_a), C.byref(p), C.c_int(int(calc_ener)),
                              _p(f), _p(vir), C.byref(vc), C.byref(vv))
     return dict(f=f, vir=vir.reshape(3, 3), Vc=vc.value, Vvdw=vv.value)

@@ -347,19 +347,27 @@ int oracle_prune_list(const float *xq, const float *shift_vec, int nsci, const n
     return 0;
 }
 
-/* Brute force over all atom pairs with the minimum-image convention in a rectangular box:
+/* Brute force over all atom pairs with the minimum-image convention:
  * the list-independent ground truth for small systems (validates list completeness and
  * exclusion masks, not only the kernel).  Atoms in caller order; excl as CSR; excluded
- * pairs inside the cut-off get the int_bit = 0 term, self pairs the self term. */
-int oracle_brute_force(int natoms, const float *x, const float *q, const int *type, int ntype,
-                       const float *nbfp, const float *box,
-                       const int *excl_index, const int *excl_a,
-                       const oracle_params_t *p, int calc_ener,
-                       double *f, double *vir /* 9, -0.5 sum r_ij (x) f_ij */, double *Vc, double *Vvdw)
+ * pairs inside the cut-off get the int_bit = 0 term, self pairs the self term.
+ * box9: the GROMACS box matrix (rows are box vectors, lower triangular).  The nearest image is
+ * searched over k box[XX] + l box[YY] + m box[ZZ] with |k| <= 2, |l|, |m| <= 1 -- the shift
+ * vectors the reference's search can use (calc_shifts, gmxlib/pbc.c:1326-1349) -- which holds the
+ * nearest image of any two atoms in the brick [0, box[d][d]) for a box within check_box's skew
+ * limits (pbc.c:143-146). */
+static int brute_force_core(int natoms, const float *x, const float *q, const int *type, int ntype,
+                            const float *nbfp, const double box9[9],
+                            const int *excl_index, const int *excl_a,
+                            const oracle_params_t *p, int calc_ener,
+                            double *f, double *vir, double *Vc, double *Vvdw)
 {
     const double rc2 = p->rcoulomb * p->rcoulomb;
     int          i, j, k, d, e;
     double       q2 = 0;
+    const int    tric = (box9[3] != 0 || box9[6] != 0 || box9[7] != 0);
+    float        bf[9];
+    for (d = 0; d < 9; d++) { bf[d] = (float)box9[d]; }
     for (i = 0; i < natoms; i++)
     {
         q2 += (double)q[i] * q[i];
@@ -367,11 +375,37 @@ int oracle_brute_force(int natoms, const float *x, const float *q, const int *ty
         {
             double dx[3], rsq = 0, fscal, c6, c12;
             int    int_bit = 1;
-            for (d = 0; d < 3; d++)
+            for (d = 0; d < 3; d++) { dx[d] = (double)x[3 * i + d] - x[3 * j + d]; }
+            if (!tric)
             {
-                dx[d]  = (double)x[3 * i + d] - x[3 * j + d];
-                dx[d] -= box[d] * floor(dx[d] / box[d] + 0.5);
-                rsq   += dx[d] * dx[d];
+                for (d = 0; d < 3; d++)
+                {
+                    dx[d] -= box9[4 * d] * floor(dx[d] / box9[4 * d] + 0.5);
+                    rsq   += dx[d] * dx[d];
+                }
+            }
+            else
+            {
+                double best[3] = {0, 0, 0};
+                int    tx, ty, tz;
+                rsq = 1e300;
+                for (tz = -1; tz <= 1; tz++)
+                {
+                    for (ty = -1; ty <= 1; ty++)
+                    {
+                        for (tx = -2; tx <= 2; tx++)
+                        {
+                            /* the shift vector as the path has it: summed in float (calc_shifts) */
+                            const float  sx = tx * bf[0] + ty * bf[3] + tz * bf[6];
+                            const float  sy = ty * bf[4] + tz * bf[7];
+                            const float  sz = tz * bf[8];
+                            const double vx = dx[0] + sx, vy = dx[1] + sy, vz = dx[2] + sz;
+                            const double r2 = vx * vx + vy * vy + vz * vz;
+                            if (r2 < rsq) { rsq = r2; best[0] = vx; best[1] = vy; best[2] = vz; }
+                        }
+                    }
+                }
+                for (d = 0; d < 3; d++) { dx[d] = best[d]; }
             }
             if (rsq >= rc2) { continue; }
             if (excl_index)
@@ -408,6 +442,28 @@ int oracle_brute_force(int natoms, const float *x, const float *q, const int *ty
         }
     }
     return 0;
+}
+
+int oracle_brute_force(int natoms, const float *x, const float *q, const int *type, int ntype,
+                       const float *nbfp, const float *box,
+                       const int *excl_index, const int *excl_a,
+                       const oracle_params_t *p, int calc_ener,
+                       double *f, double *vir /* 9, -0.5 sum r_ij (x) f_ij */, double *Vc, double *Vvdw)
+{
+    const double b9[9] = {box[0], 0, 0, 0, box[1], 0, 0, 0, box[2]};
+    return brute_force_core(natoms, x, q, type, ntype, nbfp, b9, excl_index, excl_a, p, calc_ener, f, vir, Vc, Vvdw);
+}
+
+int oracle_brute_force_tric(int natoms, const float *x, const float *q, const int *type, int ntype,
+                            const float *nbfp, const float *box9,
+                            const int *excl_index, const int *excl_a,
+                            const oracle_params_t *p, int calc_ener,
+                            double *f, double *vir, double *Vc, double *Vvdw)
+{
+    double b9[9];
+    int    d;
+    for (d = 0; d < 9; d++) { b9[d] = box9[d]; }
+    return brute_force_core(natoms, x, q, type, ntype, nbfp, b9, excl_index, excl_a, p, calc_ener, f, vir, Vc, Vvdw);
 }
 
 /* Virial from shift forces and per-atom forces, as calc_vir does for the Verlet path

@@ -158,3 +158,49 @@ def test_errors_are_reported_not_crashed():
         h.make_pairlist(abi.LOCAL, 1.0, xq)   # box shorter than 2*rlist
     with pytest.raises(g.host.HostError):
         h.set_atomdata(3, s.type + 5, s.q)    # type outside the table
+
+
+@pytest.mark.parametrize("skew,rc,wide", [((6, -5, 4), 0.9, True), ((3, 2, -6), 0.8, False), ((0, 0, 5), 0.9, False)])
+def test_triclinic_box_list_is_complete(skew, rc, wide):
+    """Triclinic cells (nbnxn_search.c:4906-4927, :5017-5098): shift vectors are sums of box vectors, and a
+    strongly skewed box needs two box lengths in x (wide: shifts with tx = -2 occur).  The list-driven oracle
+    on the host builder's list against brute force over all atom pairs with the nearest image among the 45
+    shift vectors: same pairs, same arithmetic, so equal to double rounding."""
+    s = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=skew)
+    assert s.box.shape == (3, 3)
+    for ip in (g.system.reaction_field(rc, epsilon_rf=0.0), g.system.ewald(rc)):
+        p = g.workload.prepare(s, ip, 300)
+        _check_list_invariants(p)
+        tx = p.pl.sci["shift"] % 5 - 2
+        assert (tx.min() == -2) == wide
+        o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+        b = O.brute_force(s.x, s.q, s.type, p.ntype, p.nbfp, s.box, s.excl_index, s.excl_a, ip)
+        fb = np.zeros_like(o["f"])
+        fb[p.host.cell_index()] = b["f"]
+        assert relrms(o["f"], fb) < 1e-12
+        assert abs(o["Vc"] - b["Vc"]) < 1e-10 * abs(b["Vc"])
+        assert abs(o["Vvdw"] - b["Vvdw"]) < 1e-10 * abs(b["Vvdw"])
+    # calc_shifts (gmxlib/pbc.c:1326-1349)
+    sv = p.host.shift_vec()
+    for tz in (-1, 0, 1):
+        for ty in (-1, 0, 1):
+            for tx_ in (-2, -1, 0, 1, 2):
+                want = tx_ * s.box[0] + ty * s.box[1] + tz * s.box[2]
+                assert np.allclose(sv[5 * (3 * (tz + 1) + ty + 1) + tx_ + 2], want, rtol=0, atol=1e-6)
+
+
+def test_triclinic_box_refusals():
+    L = 3.0
+    ok = np.array([[L, 0, 0], [1.0, L, 0], [-1.0, 1.2, L]], dtype=np.float32)
+    g.host.NbnxnHost(ok)
+    for bad in (np.array([[L, 0.1, 0], [0, L, 0], [0, 0, L]]),          # first vector not along x
+                np.array([[L, 0, 0], [1.6, L, 0], [0, 0, L]]),          # check_box: too skewed
+                np.array([[L, 0, 0], [0, L, 0], [0, -1.6, L]])):
+        with pytest.raises(g.host.HostError):
+            g.host.NbnxnHost(bad.astype(np.float32))
+    with pytest.raises(g.host.HostError):
+        g.host.NbnxnHost(ok, pbc_shift_dim=(1, 1, 0))                  # a skewed z vector needs shifts in z
+    # half the shortest box vector bounds the list radius (max_cutoff2, gmxlib/pbc.c:158-185)
+    s = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(0, 0, 6))
+    with pytest.raises(g.host.HostError):
+        g.workload.prepare(s, g.system.reaction_field(1.2, rlist=1.6, epsilon_rf=0.0), 0)
