@@ -1144,7 +1144,7 @@ int nbnxn_hip_set_atom_order(nbnxn_hip_ptr_t nb, int natoms_real, const int *a, 
 
 // ---- pair search on the device ----
 
-int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int nzones,
+int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[9], const int pbc_shift_dim[3], int nzones,
                                 const nbx_grid_zone_t *zones, int natoms, const float *x, int x_on_device, const int *type,
                                 const float *q)
 {
@@ -1224,7 +1224,7 @@ int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const in
     HIP_TRY(hipMemcpyAsync(nb->d_a.p, nbx_search_atom_order(nb->search), (size_t)npad * sizeof(int), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(nb->d_cell.p, nbx_search_cell_index(nb->search), (size_t)natoms * sizeof(int), hipMemcpyDeviceToDevice, st));
     nb->natoms_real = natoms;
-    // shift vectors of the rectangular box, XYZ2IS order (types/ishift.h:45-55)
+    // shift vectors of the box, XYZ2IS order (types/ishift.h:45-55), summed as calc_shifts does (gmxlib/pbc.c:1326-1349)
     float sv[NBX_SHIFTS * 3];
     int   is = 0;
     for (int tz = -1; tz <= 1; tz++)
@@ -1233,7 +1233,9 @@ int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const in
         {
             for (int tx = -2; tx <= 2; tx++, is++)
             {
-                sv[3 * is] = tx * box[0]; sv[3 * is + 1] = ty * box[1]; sv[3 * is + 2] = tz * box[2];
+                sv[3 * is]     = tx * box[0] + ty * box[3] + tz * box[6];
+                sv[3 * is + 1] = ty * box[4] + tz * box[7];
+                sv[3 * is + 2] = tz * box[8];
             }
         }
     }
@@ -1244,12 +1246,12 @@ int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const in
     return 0;
 }
 
-int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
+int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[9], const int pbc_shift_dim[3], int natoms, const float *x,
                           int x_on_device, const int *type, const float *q, float atom_density)
 {
     if (!box) { return nbx_fail("put_on_grid: missing box"); }
     nbx_grid_zone_t z;
-    for (int d = 0; d < 3; d++) { z.corner0[d] = 0; z.corner1[d] = box[d]; }
+    for (int d = 0; d < 3; d++) { z.corner0[d] = 0; z.corner1[d] = box[4 * d]; }
     z.a0 = 0; z.n = natoms; z.atom_density = atom_density;
     return nbnxn_hip_put_on_grid_zones(nb, box, pbc_shift_dim, 1, &z, natoms, x, x_on_device, type, q);
 }

@@ -21,7 +21,7 @@ const char *nbx_search_error();
 // (0 = home, then the halo zones as the domain decomposition numbers them); zone 0 starts a new search and takes the
 // box and the periodic dimensions.  d_x is [all atoms][3] in caller order, on the device.  Synchronises the stream
 // once (the padded atom count sizes the caller's arrays).  ALL zones get their columns before any is filled.
-int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[3], const int pbc_shift_dim[3],
+int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[9], const int pbc_shift_dim[3],
                             const float corner0[3], const float corner1[3], int a0, int n, const float *d_x, float atom_density);
 int nbx_search_natoms_padded(const nbx_search *s);         // all zones
 int nbx_search_natoms_padded_local(const nbx_search *s);   // home zone

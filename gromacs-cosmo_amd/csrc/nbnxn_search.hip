@@ -33,6 +33,7 @@ constexpr int   NSUBC    = NBX_NCL_PER_SUPERCL;
 constexpr int   NA_SC    = NA_C * NSUBC;
 constexpr float FAR_AWAY = 107.0f;   // nbnxn_atomdata.c:256
 constexpr int   NSHIFT_HALF = 14;    // shifts <= CENTRAL with |t| <= 1 in every dimension
+constexpr int   NSHIFT_HALF_WIDE = 23;   // shifts <= CENTRAL with |tx| <= 2: all shift indices 0..22
 
 thread_local std::string g_err;
 
@@ -90,7 +91,9 @@ struct ListParams {
     int        nci;       // super-cells of the i-zone (the home zone, cell0 = 0)
     int        njz;       // j-zones of this list: 1 (the home zone itself) or the halo zones
     int        same;      // the j-zone is the i-zone: half list, 14 shifts; otherwise all 27 shifts
-    float      box[3];
+    int        wide;      // a skewed box that needs two box lengths in x (shp[0] == 2): 23 / 45 shifts instead
+    float      box[3];    // the diagonal
+    float      byx, bzx, bzy;   // box[YY][XX], box[ZZ][XX], box[ZZ][YY] of a triclinic box
     int        shp[3];
     float      rlist, rl2;
     ZoneParams zp[MAX_ZONES];
@@ -108,15 +111,28 @@ __device__ __constant__ signed char c_shift_t[NSHIFT_HALF][3] = {
 
 __device__ __forceinline__ int shift_index(int tx, int ty, int tz) { return 5 * (3 * (tz + 1) + ty + 1) + tx + 2; }
 
-__device__ __forceinline__ int entries_per_cell(int same, int njz) { return same ? NSHIFT_HALF : 27 * njz; }
+// how entry numbers map to (i super-cell, j-zone, shift)
+struct EntryMap { int same, njz, wide; };
 
-__device__ __forceinline__ Entry decode_entry(int e, int same, int njz)
+__host__ __device__ __forceinline__ int entries_per_cell(EntryMap m)
+{
+    return m.same ? (m.wide ? NSHIFT_HALF_WIDE : NSHIFT_HALF) : (m.wide ? 45 : 27) * m.njz;
+}
+
+__device__ __forceinline__ Entry decode_entry(int e, EntryMap m)
 {
     Entry     en;
-    const int per = entries_per_cell(same, njz);
+    const int per = entries_per_cell(m);
     en.sci        = e / per;
     const int r   = e - en.sci * per;
-    if (same)
+    if (m.wide)
+    {
+        // tx = -2..2: the slot within a zone IS the shift index (XYZ2IS), 0..22 for a half list
+        en.jzi = m.same ? 0 : r / 45;
+        const int ss = r - en.jzi * 45;
+        en.tx = ss % 5 - 2; en.ty = (ss / 5) % 3 - 1; en.tz = ss / 15 - 1;
+    }
+    else if (m.same)
     {
         en.jzi = 0;
         en.tx = c_shift_t[r][0]; en.ty = c_shift_t[r][1]; en.tz = c_shift_t[r][2];
@@ -391,7 +407,7 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
 {
     const int e    = blockIdx.x;
     const int lane = threadIdx.x;
-    const Entry en = decode_entry(e, P.same, P.njz);
+    const Entry en = decode_entry(e, EntryMap{P.same, P.njz, P.wide});
     const int   sci = en.sci, tx = en.tx, ty = en.ty, tz = en.tz;
     const ZoneParams &Z = P.zp[en.jzi];
     const int *__restrict__ cxy_ind = Z.cxy_ind;
@@ -404,7 +420,8 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
         return;
     }
     const int   shift = shift_index(tx, ty, tz);
-    const float sh[3] = {tx * P.box[0], ty * P.box[1], tz * P.box[2]};
+    // shx, shy, shz (nbnxn_search.c:5019, :5054, :5098), the host builder's expressions term for term
+    const float sh[3] = {tx * P.box[0] + ty * P.byx + tz * P.bzx, ty * P.box[1] + tz * P.bzy, tz * P.box[2]};
     const bool  central = P.same && (shift == NBX_CENTRAL);   // half list only within one grid
 
     // box of the whole i super-cell (unshifted union of its clusters' boxes, from the gridding pass), then shifted
@@ -589,7 +606,7 @@ __device__ __forceinline__ int cj_at(const nbx_cj4_t *cj4, int ind) { return cj4
 // the j > i masks of the entry's own clusters, set_self_and_newton_excls_supersub).
 template <bool APPLY>
 __global__ void __launch_bounds__(64)
-k_excl(int natoms, int same, int njz, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
+k_excl(int natoms, EntryMap em, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
        const int *__restrict__ a, const int *__restrict__ cell, const int *__restrict__ excl_index,
        const int *__restrict__ excl_a, int *__restrict__ need_excl, nbx_excl_t *__restrict__ excl)
 {
@@ -597,9 +614,9 @@ k_excl(int natoms, int same, int njz, const int *__restrict__ ncj, const int *__
     const int lane = threadIdx.x;
     const int n    = ncj[e];
     if (n == 0) { return; }
-    const Entry en     = decode_entry(e, same, njz);
+    const Entry en     = decode_entry(e, em);
     const int  sci     = en.sci;
-    const bool central = same && shift_index(en.tx, en.ty, en.tz) == NBX_CENTRAL;
+    const bool central = em.same && shift_index(en.tx, en.ty, en.tz) == NBX_CENTRAL;
     const int  first   = cj4_start[e] * 4, last = first + n - 1;
 
     if (APPLY && central)
@@ -689,7 +706,7 @@ __device__ __forceinline__ int progressive_nsp_max(int nsp_max_av, int sci, int 
 // split_sci_entry, one thread per entry.  WRITE = false: nparts[e]; WRITE = true: the entry's
 // nbnxn_sci_t parts at part_start[e].
 template <bool WRITE>
-__global__ void k_split(int nentries, int same, int njz, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
+__global__ void k_split(int nentries, EntryMap em, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
                         const nbx_cj4_t *__restrict__ cj4, int nsp_max_av, int progressive, int *__restrict__ nparts,
                         const int *__restrict__ part_start, nbx_sci_t *__restrict__ sci_out)
 {
@@ -698,7 +715,7 @@ __global__ void k_split(int nentries, int same, int njz, const int *__restrict__
     if (e == nentries) { if (!WRITE) { nparts[e] = 0; } return; }
     const int n = ncj[e];
     if (n == 0) { if (!WRITE) { nparts[e] = 0; } return; }
-    const Entry en  = decode_entry(e, same, njz);
+    const Entry en  = decode_entry(e, em);
     const int sci   = en.sci;
     const int shift = shift_index(en.tx, en.ty, en.tz);
     const int nsp_max = progressive ? progressive_nsp_max(nsp_max_av, sci, shift) : nsp_max_av;
@@ -775,7 +792,8 @@ struct Zone {
 };
 
 struct nbx_search {
-    float box[3] = {0, 0, 0};
+    float box[3] = {0, 0, 0};          // the diagonal
+    float byx = 0, bzx = 0, bzy = 0;   // box[YY][XX], box[ZZ][XX], box[ZZ][YY]
     int   shp[3] = {1, 1, 1};
     int   nzones = 0, nzones_filled = 0;
     int   natoms = 0;      // atoms of all zones gridded so far
@@ -815,7 +833,7 @@ const char *nbx_search_error() { return g_err.c_str(); }
 
 void nbx_search_set_progressive_balance(nbx_search *s, bool on) { if (s) { s->progressive = on; } }
 
-int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[3], const int pbc_shift_dim[3],
+int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float box[9], const int pbc_shift_dim[3],
                             const float corner0[3], const float corner1[3], int a0, int n, const float *d_x, float atom_density)
 {
     if (!s) { return sfail("null search handle"); }
@@ -824,10 +842,29 @@ int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float
     {
         for (int d = 0; d < 3; d++)
         {
-            if (!(box[d] > 0)) { return sfail("box[%d] = %g must be > 0", d, box[d]); }
-            s->box[d] = box[d];
+            if (!(box[4 * d] > 0)) { return sfail("box[%d][%d] = %g must be > 0", d, d, box[4 * d]); }
+        }
+        // check_box (gmxlib/pbc.c:121-156), as the host-side builder applies it
+        if (box[1] != 0 || box[2] != 0 || box[5] != 0)
+        {
+            return sfail("Only triclinic boxes with the first vector parallel to the x-axis and the second vector in the xy-plane are supported.");
+        }
+        const float margin = 1.0010f;   // BOX_MARGIN, pbc.c:68
+        if (std::fabs(box[3]) > margin * 0.5f * box[0] || std::fabs(box[6]) > margin * 0.5f * box[0] || std::fabs(box[7]) > margin * 0.5f * box[4])
+        {
+            return sfail("Triclinic box is too skewed.");
+        }
+        if ((box[3] != 0 && !(pbc_shift_dim[0] && pbc_shift_dim[1]))
+            || ((box[6] != 0 || box[7] != 0) && !(pbc_shift_dim[0] && pbc_shift_dim[1] && pbc_shift_dim[2])))
+        {
+            return sfail("a triclinic box vector needs periodic shifts in the dimensions it couples");
+        }
+        for (int d = 0; d < 3; d++)
+        {
+            s->box[d] = box[4 * d];
             s->shp[d] = pbc_shift_dim[d] ? 1 : 0;
         }
+        s->byx = box[3]; s->bzx = box[6]; s->bzy = box[7];
         s->nzones = 0; s->nzones_filled = 0; s->natoms = 0; s->nc = 0; s->nsubc_tot0 = -1;
         if (s->counters.reserve(16)) { return 1; }
         S_TRY(hipMemsetAsync(s->counters.p, 0, 16 * sizeof(int), st));
@@ -978,6 +1015,10 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
             return sfail("box[%d] = %g is shorter than 2*rlist = %g: more than one periodic image in range", d, s->box[d], 2 * rlist);
         }
     }
+    if (s->shp[1] && s->shp[2] && s->box[1] - std::fabs(s->bzy) < rlist)
+    {
+        return sfail("box[YY][YY] - |box[ZZ][YY]| = %g is shorter than rlist = %g", s->box[1] - std::fabs(s->bzy), rlist);
+    }
     const Zone &zi = s->zone[0];
     ListParams  P;
     memset(&P, 0, sizeof(P));
@@ -985,6 +1026,11 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     P.same = same ? 1 : 0;
     P.njz  = same ? 1 : s->nzones - 1;
     for (int d = 0; d < 3; d++) { P.box[d] = s->box[d]; P.shp[d] = s->shp[d]; }
+    P.byx = s->byx; P.bzx = s->bzx; P.bzy = s->bzy;
+    // shift range (nbnxn_search.c:4906-4927): a skewed box can need two box lengths in x
+    if (P.shp[0] && s->box[0] - std::fabs(s->byx) - std::fabs(s->bzx) < rlist) { P.shp[0] = 2; }
+    P.wide = (P.shp[0] == 2) ? 1 : 0;
+    const EntryMap em{P.same, P.njz, P.wide};
     P.rlist = rlist;
     P.rl2   = rlist * rlist;
     for (int k = 0; k < P.njz; k++)
@@ -998,7 +1044,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
         const float r   = std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby));
         zp.rbb2 = r * r;
     }
-    const int nent = zi.nc * (same ? NSHIFT_HALF : 27 * P.njz);
+    const int nent = zi.nc * entries_per_cell(em);
     int      *cnt  = s->counters.p;   // [1] nci_tot of the list being made, [2 + z] clusters with atoms of zone z
 
     if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)
@@ -1022,9 +1068,9 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
     hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
                        s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1));
-    hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+    hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
-    hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p,
+    hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, em, s->ncj.p, s->cj4_start.p, s->cj4.p,
                        nsp_max, s->progressive ? 1 : 0, s->nparts.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
     S_TRY(hipGetLastError());
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->need_excl.p, s->excl_rank.p, 2 * ncj4 + 1, st));
@@ -1040,9 +1086,9 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
         || s->skey_out.reserve((size_t)nsci + 1)) { return 1; }
     hipLaunchKernelGGL(k_excl_init, dim3(blocks_for(2 * (size_t)ncj4 + 1, 256)), dim3(256), 0, st, 2 * ncj4, s->need_excl.p, s->excl_rank.p,
                        s->cj4.p, s->excl.p);
-    hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+    hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, (int *)nullptr, s->excl.p);
-    hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, P.same, P.njz, s->ncj.p, s->cj4_start.p, s->cj4.p,
+    hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, em, s->ncj.p, s->cj4_start.p, s->cj4.p,
                        nsp_max, s->progressive ? 1 : 0, (int *)nullptr, s->part_start.p, s->sci_a.p);
     S_TRY(hipGetLastError());
     const nbx_sci_t *sci_final = s->sci_a.p;

@@ -191,10 +191,16 @@ class NbnxnHip:
         self._chk(self.lib.nbnxn_hip_launch_kernel_pruneonly(self.h, iloc, rlist_inner, num_parts))
 
     # ---- pair search on the device (SURVEY 8f-2) ----
+    @staticmethod
+    def _box_matrix(box):
+        """[3] (rectangular) or [3, 3] (GROMACS matrix, rows are box vectors) -> the 9 floats the C ABI takes"""
+        box = np.asarray(box, dtype=np.float32)
+        return np.ascontiguousarray(np.diag(box) if box.shape == (3,) else box, dtype=np.float32).reshape(9)
+
     def put_on_grid(self, box, x, type_, q, pbc_shift_dim=None, atom_density=0.0):
         """nbnxn_put_on_grid + nbnxn_atomdata_set + init_atomdata + copy_x on the device.  x: numpy
         [n,3] or an object with __cuda_array_interface__ (device array).  Returns the padded atom count."""
-        box = np.ascontiguousarray(box, dtype=np.float32)
+        box = self._box_matrix(box)
         if type_ is not None:
             type_ = np.ascontiguousarray(type_, dtype=np.int32)
             q = np.ascontiguousarray(q, dtype=np.float32)
@@ -216,7 +222,7 @@ class NbnxnHip:
     def put_on_grid_zones(self, box, zones, x, type_, q, pbc_shift_dim=None):
         """zones: list of (corner0, corner1, a0, n) -- home zone first, then the halo zones; x / type_ / q hold all
         their atoms in that order.  Returns (padded atoms of all zones, padded atoms of the home zone)."""
-        box = np.ascontiguousarray(box, dtype=np.float32)
+        box = self._box_matrix(box)
         if type_ is not None:
             type_ = np.ascontiguousarray(type_, dtype=np.int32)
             q = np.ascontiguousarray(q, dtype=np.float32)

@@ -265,6 +265,24 @@ def water_box(nx, ny, nz, model="spc"):
                   excl_index=excl_index, excl_a=excl_a, name=f"{model}216x{nx}x{ny}x{nz}")
 
 
+def put_atoms_in_box(x, box):
+    """put_atoms_in_box (gmxlib/pbc.c:1562-1625) in float32: every atom shifted by whole box vectors, from z down
+    to x, into the brick [0, box[d][d]).  box: [3] or the [3, 3] matrix (rows are box vectors)."""
+    x = np.array(x, dtype=np.float32)
+    b = np.asarray(box, dtype=np.float32)
+    if b.shape == (3,):
+        b = np.diag(b)
+    for m in (2, 1, 0):
+        while True:
+            lo = x[:, m] < 0
+            hi = x[:, m] >= b[m, m]
+            if not (lo.any() or hi.any()):
+                break
+            x[lo, :m + 1] += b[m, :m + 1]
+            x[hi, :m + 1] -= b[m, :m + 1]
+    return x
+
+
 def lj_chain_mixture(natoms, ntype=8, seed=2026, density=100.0, chain_len=(12, 40), skew=None):
     """Config-5-like synthetic system: an ntype-type LJ mixture of chain molecules with
     1-2 and 1-3 exclusions and partial charges, on a jittered lattice (no reference fixture

@@ -450,15 +450,17 @@ int nbnxn_hip_get_output_slots(nbnxn_hip_ptr_t nb, void **d_out, int *nslots, in
  * + nbnxn_cuda_init_pairlist (nbnxn_cuda_data_mgmt.h:75): atoms and list never visit the host.
  * ---------------------------------------------------------------------------------- */
 
-/* Grids natoms atoms of a rectangular box [0, box) into columns / super-cells / clusters exactly
- * as the host-side builder (include/nbnxn_host.h) does, and fills the module's grid-ordered
+/* Grids natoms atoms into columns / super-cells / clusters exactly as the host-side builder
+ * (include/nbnxn_host.h) does.  box[9] is the GROMACS box matrix as nbnxn_put_on_grid takes it
+ * (rows are box vectors; rectangular or triclinic within check_box's limits, gmxlib/pbc.c:121-156);
+ * the atoms lie in the brick [0, box[d][d]) that put_atoms_in_box leaves them in.  The call also fills the module's grid-ordered
  * coordinates+charges (with fillers), types (dummy type = ntype - 1 of init_const), atom-order
  * arrays (as nbnxn_hip_set_atom_order would) and shift vectors.  x [natoms][3] may be a host or a
  * device array; type and q are host arrays in caller order; pbc_shift_dim NULL = periodic in
  * x, y and z; atom_density <= 0 = natoms / volume.  type = q = NULL reuses the arrays of the last
  * call (the topology is constant between searches; natoms must agree).  Invalidates the lists.
  * Call after init_const. */
-int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int natoms, const float *x,
+int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[9], const int pbc_shift_dim[3], int natoms, const float *x,
                           int x_on_device, const int *type, const float *q, float atom_density);
 
 /* The same for a domain with halo zones, as nbnxn_put_on_grid is called once per zone
@@ -473,7 +475,7 @@ typedef struct {
     int   a0, n;
     float atom_density;
 } nbx_grid_zone_t;
-int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[3], const int pbc_shift_dim[3], int nzones,
+int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[9], const int pbc_shift_dim[3], int nzones,
                                 const nbx_grid_zone_t *zones, int natoms, const float *x, int x_on_device, const int *type,
                                 const float *q);
 

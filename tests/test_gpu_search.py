@@ -61,6 +61,11 @@ CASES = [
     ("chains 3k", lambda: g.system.lj_chain_mixture(3000), lambda: g.system.reaction_field(0.9), 0),
     ("chains 6k split", lambda: g.system.lj_chain_mixture(6000, ntype=8, seed=11), lambda: g.system.ewald(0.9, rlist=1.05), 2000),
     ("water 97k", lambda: g.system.water_box(5, 5, 6), lambda: g.system.reaction_field(1.0), None),
+    # triclinic cells: "wide" ones need two box lengths in x (nbnxn_search.c:4917-4921)
+    ("chains 3k triclinic wide", lambda: g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, -5, 4)), lambda: g.system.reaction_field(0.9), 0),
+    ("chains 3k triclinic wide split", lambda: g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, -5, 4)),
+     lambda: g.system.ewald(0.9, rlist=1.0), 1000),
+    ("chains 6k triclinic split", lambda: g.system.lj_chain_mixture(5832, ntype=8, seed=11, skew=(4, 3, -7)), lambda: g.system.ewald(0.9, rlist=1.0), 2000),
 ]
 
 
@@ -98,6 +103,40 @@ def test_device_grid_and_list_equal_the_host_builders(nb, name, make_system, mak
     fo = np.zeros((s.natoms, 3), dtype=np.float32)
     p.host.add_f(np.asarray(o["f"], dtype=np.float32), fo)
     assert relrms(fa, fo) < FORCE_RTOL
+
+
+def test_triclinic_cell_against_brute_force(nb):
+    """The whole device path on a strongly skewed cell (search on the device, list never on the host, kernel) against
+    the list-independent truth: brute force over all atom pairs with the nearest of the 45 shift images, in double.
+    Forces, energies and the virial from the shift forces (whose shift vectors are sums of box vectors here)."""
+    from util import virial_from
+    s = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, -5, 4))
+    for ip in (g.system.reaction_field(0.9, epsilon_rf=0.0), g.system.ewald(0.9)):
+        _device_search(nb, s, ip, 500)
+        tx = nb.download_pairlist().sci["shift"] % 5 - 2
+        assert tx.min() == -2
+        f = np.zeros((nb.natoms, 3), dtype=np.float32)
+        e_lj, e_el = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        fsh = np.zeros((abi.SHIFTS, 3), dtype=np.float32)
+        nb.clear_outputs(abi.FORCE_VIRIAL)
+        nb.launch_kernel_resident(abi.FORCE_VIRIAL)
+        nb.launch_cpyback(f, abi.FORCE_VIRIAL)
+        nb.wait_gpu(abi.FORCE_VIRIAL, abi.LOCAL, e_lj, e_el, fsh)
+        fa = np.zeros((s.natoms, 3), dtype=np.float32)
+        nb.add_f(fa)
+        b = O.brute_force(s.x, s.q, s.type, s.ntype + 1, s.nbfp(), s.box, s.excl_index, s.excl_a, ip)
+        assert relrms(fa, b["f"]) < FORCE_RTOL
+        assert abs(float(e_lj[0]) - b["Vvdw"]) < ENERGY_RTOL * abs(b["Vvdw"])
+        assert abs(float(e_el[0]) - b["Vc"]) < ENERGY_RTOL * abs(b["Vc"])
+        grid = nb.download_grid()
+        sv = np.array([tx_ * s.box[0] + ty * s.box[1] + tz * s.box[2] for tz in (-1, 0, 1) for ty in (-1, 0, 1) for tx_ in (-2, -1, 0, 1, 2)],
+                      dtype=np.float32)
+        vir = virial_from(grid["xq"], f, sv, fsh)
+        assert np.abs(vir - b["vir"]).max() < ENERGY_RTOL * np.abs(b["vir"]).max()
+    with pytest.raises(g.gpu.HipError):
+        nb.put_on_grid(np.array([[3, 0, 0], [1.6, 3, 0], [0, 0, 3]], dtype=np.float32), s.x, s.type, s.q)     # too skewed
+    with pytest.raises(g.gpu.HipError):
+        nb.put_on_grid(s.box, s.x, s.type, s.q, pbc_shift_dim=(1, 1, 0))    # a skewed z vector needs shifts in z
 
 
 def test_device_search_edge_cases(nb):
@@ -171,7 +210,7 @@ def test_device_search_refusals(nb):
         nb.make_pairlist(ip.rlist, s.excl_index, s.excl_a, 0)
 
 
-@pytest.mark.parametrize("kind", ["water", "chains"])
+@pytest.mark.parametrize("kind", ["water", "chains", "triclinic"])
 def test_verlet_loop_with_moving_atoms(nb, kind):
     """The callers either side of the kernel in the reference's order (gromacs-cosmo_amd/verlet.py = the
     device-resident do_force_cutsVERLET): search every 5 steps with a 0.1 nm buffer, atoms drifting in between
@@ -181,6 +220,8 @@ def test_verlet_loop_with_moving_atoms(nb, kind):
     import torch
     if kind == "water":
         s, base = g.system.water_box(2, 2, 2, model="spce"), g.system.ewald(0.9)
+    elif kind == "triclinic":
+        s, base = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, -5, 4)), g.system.ewald(0.9)
     else:
         s, base = g.system.lj_chain_mixture(3000), g.system.reaction_field(0.9)
     ip = dataclasses.replace(base, rlist=1.0)
@@ -191,13 +232,13 @@ def test_verlet_loop_with_moving_atoms(nb, kind):
     vel = rng.normal(0, 0.004, x.shape).astype(np.float32)   # <= ~0.015 nm per step, 4 steps between searches
     for step in range(11):
         if step % 5 == 0:
-            x = np.mod(x, s.box).astype(np.float32)         # put_atoms_in_box on search steps
+            x = g.system.put_atoms_in_box(x, s.box)         # as the reference does on search steps
         xd = torch.from_numpy(x).cuda()
         fd = torch.zeros_like(xd)
         e = loop.force(xd, fd, abi.FORCE_VIRIAL)
         torch.cuda.synchronize()
         f = fd.cpu().numpy()
-        p = g.workload.prepare(dataclasses.replace(s, x=np.mod(x, s.box).astype(np.float32)), ip_exact, 0)
+        p = g.workload.prepare(dataclasses.replace(s, x=g.system.put_atoms_in_box(x, s.box)), ip_exact, 0)
         o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip_exact)
         fo = np.zeros((s.natoms, 3), dtype=np.float32)
         p.host.add_f(np.asarray(o["f"], dtype=np.float32), fo)

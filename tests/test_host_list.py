@@ -204,3 +204,17 @@ def test_triclinic_box_refusals():
     s = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(0, 0, 6))
     with pytest.raises(g.host.HostError):
         g.workload.prepare(s, g.system.reaction_field(1.2, rlist=1.6, epsilon_rf=0.0), 0)
+
+
+def test_put_atoms_in_box_triclinic():
+    """put_atoms_in_box (gmxlib/pbc.c:1562-1625): whole box vectors only, result in the brick [0, box[d][d])"""
+    box = np.array([[3.0, 0, 0], [1.2, 2.8, 0], [-0.9, 1.1, 2.5]], dtype=np.float32)
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-7, 7, (2000, 3)).astype(np.float32)
+    y = g.system.put_atoms_in_box(x, box)
+    assert (y >= 0).all() and (y < np.diag(box)).all()
+    k = (y.astype(np.float64) - x) @ np.linalg.inv(box.astype(np.float64))
+    assert np.abs(k - np.round(k)).max() < 1e-5
+    assert np.array_equal(g.system.put_atoms_in_box(y, box), y)
+    r = g.system.put_atoms_in_box(x, np.diag(box))
+    assert (r >= 0).all() and (r < np.diag(box)).all() and np.abs(r - np.mod(x, np.diag(box))).max() < 1e-5

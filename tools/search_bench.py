@@ -24,7 +24,7 @@ for tiles in cases:
     for it in range(6):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nb.lib.nbnxn_hip_put_on_grid(nb.h, abi.ptr(np.ascontiguousarray(s.box, np.float32)), None, s.natoms,
+        nb.lib.nbnxn_hip_put_on_grid(nb.h, abi.ptr(nb._box_matrix(s.box)), None, s.natoms,
                                      xd.data_ptr(), 1, abi.ptr(s.type) if it == 0 else None, abi.ptr(s.q) if it == 0 else None, 0.0)
         t1 = time.perf_counter()
         if it == 0:
