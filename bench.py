@@ -216,6 +216,7 @@ def main():
     else:
         from gromacs_cosmo_amd import dd
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags)
+        run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
         pair_slots = run.pair_slots_local    # summed over ranks below
         roof_slots = run.dom.pl_local.nci_tot * 64   # the timed kernel is this rank's LOCAL-list launch
