@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant for A/B runs (-1: library default)")
     ap.add_argument("--event-every", type=int, default=10,
                     help="bracket the kernel of every Nth timed step with HIP events (an event pair costs device time itself)")
+    ap.add_argument("--dd-self", action="store_true",
+                    help="measurement aid: the domain-decomposed step on ONE rank that is its own neighbour (periodic in z through "
+                         "a halo of its own atoms), so the messages are real RCCL sends / receives on a one-GPU box")
     ap.add_argument("--mcb", type=int, default=-1, help="list split target (-1: nbnxn_hip_min_ci_balanced)")
     args = ap.parse_args()
 
@@ -171,8 +174,12 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    decomposed = world > 1 or args.dd_self
+    if decomposed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -185,7 +192,7 @@ def main():
     ip = g.system.ewald(1.0) if args.workload == "ewald" else g.system.reaction_field(1.0)
     flops_pair = FLOPS[(args.workload, ener)]
 
-    if world == 1:
+    if not decomposed:
         system = g.system.water_box(*tiles, model=model)
         nb = g.gpu.NbnxnHip(local_rank)
         nb.set_timing(False)     # the module's own per-launch event pair costs ~7 us of device time a step
@@ -215,7 +222,11 @@ def main():
         cfg_extra = {"nsci": prep.pl.nsci, "ncj4": prep.pl.ncj4, "cluster_pairs": prep.pl.nci_tot}
     else:
         from gromacs_cosmo_amd import dd
-        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags)
+        # the halo messages and the slot reduction are issued by the HIP module on its own RCCL communicator
+        # (nbnxn_hip_dd_*); BENCH_DD_TORCH=1 (and the one-GPU rehearsal, where RCCL cannot run two ranks on one
+        # device) sends them through torch.distributed instead
+        rccl_direct = not rehearsal and os.environ.get("BENCH_DD_TORCH") != "1"
+        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct)
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
         pair_slots = run.pair_slots_local    # summed over ranks below
@@ -223,7 +234,7 @@ def main():
         step = run.step          # step(ev) records ev around the local kernel
         stream = torch.cuda.ExternalStream(run.nb.stream(abi.LOCAL))
         sync = lambda: torch.cuda.synchronize()
-        parallelism = f"dd{world} (z slabs, RCCL halo x/f)"
+        parallelism = f"dd{world}{' (one rank, its own neighbour)' if world == 1 else ''} (z slabs, RCCL halo x/f " + ("issued by the HIP module)" if rccl_direct else "through torch.distributed)")
         cfg_extra = run.describe()
         if args.mcb >= 0 or args.variant >= 0 or args.no_split:
             raise SystemExit("--mcb/--variant/--no-split are single-GPU A/B switches")
@@ -231,7 +242,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if decomposed:
         dist.barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
@@ -239,7 +250,7 @@ def main():
     for k in range(args.steps):
         step(ev[k] if k % args.event_every == 0 else None)
     sync()
-    if world > 1:
+    if decomposed:
         dist.barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
@@ -254,7 +265,7 @@ def main():
     event_pair_ms = float(np.median([a.elapsed_time(b) for a, b in cal]))
     kernel_ms = max(kernel_ms_raw - event_pair_ms, 1e-6)
 
-    if world > 1:
+    if decomposed:
         t = torch.tensor([wall, float(pair_slots), kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,7 +280,7 @@ def main():
     # under profiles/ and quoted only when the workload is the one it was measured on
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r1_c_hbm_traffic.json")
-    if world == 1 and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
+    if not decomposed and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
             and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
 
@@ -297,7 +308,7 @@ def main():
                          "kernel_ms": kernel_ms, "kernel_ms_events_raw": kernel_ms_raw, "event_pair_ms": event_pair_ms,
                          "note": "algorithmic flops = pair slots x nrnb.c cost (gmxlib/nrnb.c:101-106); duration = mean HIP-event time around the nonbonded kernel launch inside the timed region minus the latency of an empty event pair"},
         }
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not decomposed:
             cb = cpu_baseline(prep, ip)
             out["cpu_baseline"] = cb
             chk = oracle_check(prep, ip, f0, e0)
@@ -306,7 +317,7 @@ def main():
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
             out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)
         print(json.dumps(out))
-    if world > 1:
+    if decomposed:
         dist.destroy_process_group()
 
 

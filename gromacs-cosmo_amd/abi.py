@@ -21,6 +21,7 @@ FORCE_ENERGY = 1 << 9
 LOCAL, NONLOCAL = 0, 1
 # accumulation slots of the device output buffer (csrc/nbnxn_kernel.h)
 OUT_SLOTS, OUT_STRIDE = 64, 144
+DD_UNIQUE_ID_BYTES = 128   # NBX_DD_UNIQUE_ID_BYTES
 EL_RF, EL_EWALD_ANA, EL_EWALD_TAB = 0, 1, 2
 EEL_CUT, EEL_RF, EEL_GRF, EEL_PME, EEL_EWALD = 0, 1, 2, 3, 4
 VDW_CUT, VDW_PME = 0, 5

@@ -49,28 +49,30 @@ __global__ void __launch_bounds__(256) nbnxn_scatter_f(const int *__restrict__ c
 //   pack_f:   buf[i] = f[slot[i]]                       (the importer's side of dd_move_f)
 //   unpack_f: f[slot[i]] += buf[i], and with WRAP the sum of buf goes to one shift-force entry
 //             (what dd_move_f does for a pulse that crosses a periodic boundary, :837-851)
-__global__ void __launch_bounds__(256) nbnxn_halo_pack_x(const int *__restrict__ slot, int n, const float4 *__restrict__ xq,
+// One-wave workgroups: they run beside force kernels that hold every wave slot, and a single wave fits
+// into whichever slot frees up, where a 256-thread workgroup would wait for four free slots on one CU.
+__global__ void __launch_bounds__(64) nbnxn_halo_pack_x(const int *__restrict__ slot, int n, const float4 *__restrict__ xq,
                                                          float sx, float sy, float sz, float4 *__restrict__ buf)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) { return; }
     float4 v = xq[slot[i]];
     v.x += sx; v.y += sy; v.z += sz;
     buf[i] = v;
 }
 
-__global__ void __launch_bounds__(256) nbnxn_halo_unpack_x(const int *__restrict__ slot, int n, const float4 *__restrict__ buf,
+__global__ void __launch_bounds__(64) nbnxn_halo_unpack_x(const int *__restrict__ slot, int n, const float4 *__restrict__ buf,
                                                            float4 *__restrict__ xq)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) { return; }
     xq[slot[i]] = buf[i];
 }
 
-__global__ void __launch_bounds__(256) nbnxn_halo_pack_f(const int *__restrict__ slot, int n, const float *__restrict__ f,
+__global__ void __launch_bounds__(64) nbnxn_halo_pack_f(const int *__restrict__ slot, int n, const float *__restrict__ f,
                                                          float *__restrict__ buf)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) { return; }
     const int s = slot[i];
     buf[3 * i + 0] = f[3 * s + 0];
@@ -79,12 +81,12 @@ __global__ void __launch_bounds__(256) nbnxn_halo_pack_f(const int *__restrict__
 }
 
 // The force kernels may still be adding to f on the other stream: atomic adds (one address per
-// thread, no contention).  WRAP: block sum in double, one float atomic per block and component.
+// thread, no contention).  WRAP: wave sum in double, one float atomic per wave and component.
 template <bool WRAP>
-__global__ void __launch_bounds__(256) nbnxn_halo_unpack_f(const int *__restrict__ slot, int n, const float *__restrict__ buf,
+__global__ void __launch_bounds__(64) nbnxn_halo_unpack_f(const int *__restrict__ slot, int n, const float *__restrict__ buf,
                                                            float *__restrict__ f, float *__restrict__ fshift_entry)
 {
-    const int i  = blockIdx.x * 256 + threadIdx.x;
+    const int i  = blockIdx.x * 64 + threadIdx.x;
     float     fx = 0, fy = 0, fz = 0;
     if (i < n)
     {
@@ -96,7 +98,6 @@ __global__ void __launch_bounds__(256) nbnxn_halo_unpack_f(const int *__restrict
     }
     if (WRAP)
     {
-        __shared__ double part[4][3];
         double dx = fx, dy = fy, dz = fz;
         for (int o = 32; o > 0; o >>= 1)
         {
@@ -104,13 +105,11 @@ __global__ void __launch_bounds__(256) nbnxn_halo_unpack_f(const int *__restrict
             dy += __shfl_down(dy, o);
             dz += __shfl_down(dz, o);
         }
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { part[w][0] = dx; part[w][1] = dy; part[w][2] = dz; }
-        __syncthreads();
-        if (threadIdx.x < 3)
+        if (threadIdx.x == 0)
         {
-            const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-            atomicAdd(fshift_entry + threadIdx.x, (float)t);
+            atomicAdd(fshift_entry + 0, (float)dx);
+            atomicAdd(fshift_entry + 1, (float)dy);
+            atomicAdd(fshift_entry + 2, (float)dz);
         }
     }
 }
@@ -120,29 +119,29 @@ __global__ void __launch_bounds__(256) nbnxn_halo_unpack_f(const int *__restrict
 hipError_t nbx_launch_halo_pack_x(const int *slot, int n, const float4 *xq, const float *shift, float4 *buf, hipStream_t stream)
 {
     if (n <= 0) { return hipSuccess; }
-    hipLaunchKernelGGL(nbnxn_halo_pack_x, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, xq, shift[0], shift[1], shift[2], buf);
+    hipLaunchKernelGGL(nbnxn_halo_pack_x, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, xq, shift[0], shift[1], shift[2], buf);
     return hipGetLastError();
 }
 
 hipError_t nbx_launch_halo_unpack_x(const int *slot, int n, const float4 *buf, float4 *xq, hipStream_t stream)
 {
     if (n <= 0) { return hipSuccess; }
-    hipLaunchKernelGGL(nbnxn_halo_unpack_x, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, buf, xq);
+    hipLaunchKernelGGL(nbnxn_halo_unpack_x, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, buf, xq);
     return hipGetLastError();
 }
 
 hipError_t nbx_launch_halo_pack_f(const int *slot, int n, const float *f, float *buf, hipStream_t stream)
 {
     if (n <= 0) { return hipSuccess; }
-    hipLaunchKernelGGL(nbnxn_halo_pack_f, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, f, buf);
+    hipLaunchKernelGGL(nbnxn_halo_pack_f, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, f, buf);
     return hipGetLastError();
 }
 
 hipError_t nbx_launch_halo_unpack_f(const int *slot, int n, const float *buf, float *f, float *fshift_entry, hipStream_t stream)
 {
     if (n <= 0) { return hipSuccess; }
-    if (fshift_entry) { hipLaunchKernelGGL(nbnxn_halo_unpack_f<true>, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, buf, f, fshift_entry); }
-    else { hipLaunchKernelGGL(nbnxn_halo_unpack_f<false>, dim3((n + 255) / 256), dim3(256), 0, stream, slot, n, buf, f, fshift_entry); }
+    if (fshift_entry) { hipLaunchKernelGGL(nbnxn_halo_unpack_f<true>, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, buf, f, fshift_entry); }
+    else { hipLaunchKernelGGL(nbnxn_halo_unpack_f<false>, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, buf, f, fshift_entry); }
     return hipGetLastError();
 }
 

@@ -3,6 +3,8 @@
 // part of nbnxn_cuda.cu; structure is our own: one handle, two HIP streams, plain
 // hipMalloc'd arrays with 20 % over-allocation, hipEvent timing.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound at run time (dd_bind)
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -153,6 +155,15 @@ struct nbnxn_hip {
     DevBuf<int>   d_type_in, d_excl_index, d_excl_a;   // caller-order types; topology exclusions (CSR)
     DevBuf<float> d_q_in;
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
+    // domain decomposition over RCCL (nbnxn_hip_dd_*): one pulse along one dimension
+    ncclComm_t    dd_comm = nullptr;
+    int           dd_rank = -1, dd_nranks = 0;
+    int           dd_send_to = -1, dd_recv_from = -1;   // coordinates go to send_to, forces come back from it
+    int           dd_n_send = 0, dd_n_recv = 0, dd_shift_index = -1;
+    float         dd_shift[3] = {0, 0, 0};
+    bool          dd_have_pulse = false;
+    DevBuf<int>   dd_send_slots, dd_recv_slots;
+    DevBuf<float> dd_x_out, dd_x_in, dd_f_out, dd_f_in;
 
     nbx_wallclock_gpu_t timings;
 };
@@ -901,6 +912,7 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     dev_free(nb->c6grid); dev_free(nb->coulomb_tab);
     dev_free(nb->d_type_in); dev_free(nb->d_excl_index); dev_free(nb->d_excl_a); dev_free(nb->d_q_in);
     nbx_search_destroy(nb->search); nb->search = nullptr;
+    (void)nbnxn_hip_dd_finish(nb);
     if (nb->h_fa) { (void)hipHostFree(nb->h_fa); }
     if (nb->two_streams)
     {
@@ -1529,3 +1541,175 @@ int nbnxn_hip_set_kernel_variant(nbnxn_hip_ptr_t nb, int variant)
 }
 
 } // extern "C"
+
+// ---- domain decomposition over RCCL ----
+//
+// The halo exchange of one decomposed dimension, issued from this library on its own streams: what
+// dd_move_x / dd_move_f do with MPI_Sendrecv on host buffers (mdlib/domdec.c:651-875,
+// dd_sendrecv_rvec domdec_network.c:114) becomes pack kernel -> one grouped ncclSend/ncclRecv pair
+// between devices -> unpack kernel, all on the non-local stream, with no host copy and no
+// stream hand-over to another runtime.  RCCL is bound at run time (dlopen), so hosts that run one
+// GPU need no RCCL; a process that already holds an RCCL (PyTorch brings its own) shares that copy.
+
+namespace {
+
+struct RcclApi {
+    decltype(&ncclGetUniqueId)    GetUniqueId    = nullptr;
+    decltype(&ncclCommInitRank)   CommInitRank   = nullptr;
+    decltype(&ncclCommDestroy)    CommDestroy    = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart)     GroupStart     = nullptr;
+    decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
+    decltype(&ncclSend)           Send           = nullptr;
+    decltype(&ncclRecv)           Recv           = nullptr;
+    decltype(&ncclAllReduce)      AllReduce      = nullptr;
+    bool                          bound          = false;
+};
+RcclApi g_rccl;
+
+int dd_bind()
+{
+    if (g_rccl.bound) { return 0; }
+    // the copy the process already has, if any; then the system's
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) { h = dlopen("librccl.so.1", RTLD_NOW); }
+    if (!h) { h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW); }
+    if (!h) { return nbx_fail("RCCL not found: %s", dlerror()); }
+#define NBX_BIND(name)                                                                  \
+    g_rccl.name = reinterpret_cast<decltype(g_rccl.name)>(dlsym(h, "nccl" #name));      \
+    if (!g_rccl.name) { return nbx_fail("RCCL lacks nccl" #name); }
+    NBX_BIND(GetUniqueId) NBX_BIND(CommInitRank) NBX_BIND(CommDestroy) NBX_BIND(GetErrorString)
+    NBX_BIND(GroupStart) NBX_BIND(GroupEnd) NBX_BIND(Send) NBX_BIND(Recv) NBX_BIND(AllReduce)
+#undef NBX_BIND
+    g_rccl.bound = true;
+    return 0;
+}
+
+#define RCCL_TRY(call)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess) { return nbx_fail("RCCL: %s failed: %s", #call, g_rccl.GetErrorString(r_)); } \
+    } while (0)
+
+int check_dd(nbnxn_hip *nb)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!nb->dd_comm) { return nbx_fail("domain decomposition call before nbnxn_hip_dd_init"); }
+    return 0;
+}
+
+hipStream_t dd_stream(nbnxn_hip *nb, int iloc) { return nb->stream[nb->two_streams ? iloc : 0]; }
+
+} // namespace
+
+int nbnxn_hip_dd_get_unique_id(char *id128)
+{
+    if (!id128) { return nbx_fail("null id buffer"); }
+    if (dd_bind()) { return 1; }
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == NBX_DD_UNIQUE_ID_BYTES, "RCCL unique id size");
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int nbnxn_hip_dd_init(nbnxn_hip_ptr_t nb, const char *id128, int rank, int nranks)
+{
+    if (check_handle(nb)) { return 1; }
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) { return nbx_fail("dd_init: rank %d of %d", rank, nranks); }
+    if (nb->dd_comm) { return nbx_fail("dd_init: this handle already has a communicator"); }
+    if (dd_bind()) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    RCCL_TRY(g_rccl.CommInitRank(&nb->dd_comm, nranks, id, rank));
+    nb->dd_rank = rank; nb->dd_nranks = nranks;
+    return 0;
+}
+
+int nbnxn_hip_dd_finish(nbnxn_hip_ptr_t nb)
+{
+    if (!nb) { return 0; }
+    if (nb->dd_comm)
+    {
+        (void)hipSetDevice(nb->device);
+        (void)hipDeviceSynchronize();
+        (void)g_rccl.CommDestroy(nb->dd_comm);
+        nb->dd_comm = nullptr;
+    }
+    dev_free(nb->dd_send_slots); dev_free(nb->dd_recv_slots);
+    dev_free(nb->dd_x_out); dev_free(nb->dd_x_in); dev_free(nb->dd_f_out); dev_free(nb->dd_f_in);
+    nb->dd_have_pulse = false;
+    return 0;
+}
+
+int nbnxn_hip_dd_set_pulse(nbnxn_hip_ptr_t nb, int send_to, int recv_from, const int *send_slots, int n_send,
+                           const int *recv_slots, int n_recv, const float *shift, int shift_index)
+{
+    if (check_dd(nb)) { return 1; }
+    if (send_to < 0 || send_to >= nb->dd_nranks || recv_from < 0 || recv_from >= nb->dd_nranks)
+    {
+        return nbx_fail("dd_set_pulse: neighbours %d / %d outside [0, %d)", send_to, recv_from, nb->dd_nranks);
+    }
+    if (n_send < 0 || n_recv < 0 || n_send > nb->natoms || n_recv > nb->natoms || (n_send > 0 && !send_slots) || (n_recv > 0 && !recv_slots))
+    {
+        return nbx_fail("dd_set_pulse: %d / %d halo atoms on a grid of %d slots", n_send, n_recv, nb->natoms);
+    }
+    if (shift_index < -1 || shift_index >= NBX_SHIFTS) { return nbx_fail("shift index %d outside [-1, %d)", shift_index, NBX_SHIFTS); }
+    for (int i = 0; i < n_send; i++) { if (send_slots[i] < 0 || send_slots[i] >= nb->natoms) { return nbx_fail("dd_set_pulse: send slot %d outside the grid", send_slots[i]); } }
+    for (int i = 0; i < n_recv; i++) { if (recv_slots[i] < 0 || recv_slots[i] >= nb->natoms) { return nbx_fail("dd_set_pulse: receive slot %d outside the grid", recv_slots[i]); } }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
+    if (dev_reserve(nb->dd_send_slots, std::max(n_send, 1)) || dev_reserve(nb->dd_recv_slots, std::max(n_recv, 1))
+        || dev_reserve(nb->dd_x_out, (size_t)std::max(n_send, 1) * 4) || dev_reserve(nb->dd_x_in, (size_t)std::max(n_recv, 1) * 4)
+        || dev_reserve(nb->dd_f_out, (size_t)std::max(n_recv, 1) * 3) || dev_reserve(nb->dd_f_in, (size_t)std::max(n_send, 1) * 3)) { return 1; }
+    if (n_send > 0) { HIP_TRY(hipMemcpyAsync(nb->dd_send_slots.p, send_slots, (size_t)n_send * sizeof(int), hipMemcpyHostToDevice, st)); }
+    if (n_recv > 0) { HIP_TRY(hipMemcpyAsync(nb->dd_recv_slots.p, recv_slots, (size_t)n_recv * sizeof(int), hipMemcpyHostToDevice, st)); }
+    HIP_TRY(hipStreamSynchronize(st));
+    nb->dd_send_to = send_to; nb->dd_recv_from = recv_from;
+    nb->dd_n_send = n_send; nb->dd_n_recv = n_recv;
+    for (int d = 0; d < 3; d++) { nb->dd_shift[d] = shift ? shift[d] : 0.0f; }
+    nb->dd_shift_index = shift_index;
+    nb->dd_have_pulse  = true;
+    return 0;
+}
+
+int nbnxn_hip_dd_move_x(nbnxn_hip_ptr_t nb)
+{
+    if (check_dd(nb)) { return 1; }
+    if (!nb->dd_have_pulse) { return nbx_fail("dd_move_x before dd_set_pulse"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
+    HIP_TRY(nbx_launch_halo_pack_x(nb->dd_send_slots.p, nb->dd_n_send, nb->xq.p, nb->dd_shift, reinterpret_cast<float4 *>(nb->dd_x_out.p), st));
+    RCCL_TRY(g_rccl.GroupStart());
+    if (nb->dd_n_send > 0) { RCCL_TRY(g_rccl.Send(nb->dd_x_out.p, (size_t)nb->dd_n_send * 4, ncclFloat, nb->dd_send_to, nb->dd_comm, st)); }
+    if (nb->dd_n_recv > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_x_in.p, (size_t)nb->dd_n_recv * 4, ncclFloat, nb->dd_recv_from, nb->dd_comm, st)); }
+    RCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(nbx_launch_halo_unpack_x(nb->dd_recv_slots.p, nb->dd_n_recv, reinterpret_cast<const float4 *>(nb->dd_x_in.p), nb->xq.p, st));
+    return 0;
+}
+
+int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb)
+{
+    if (check_dd(nb)) { return 1; }
+    if (!nb->dd_have_pulse) { return nbx_fail("dd_move_f before dd_set_pulse"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
+    HIP_TRY(nbx_launch_halo_pack_f(nb->dd_recv_slots.p, nb->dd_n_recv, nb->f.p, nb->dd_f_out.p, st));
+    // the reverse path: forces on imported atoms go back to where the coordinates came from
+    RCCL_TRY(g_rccl.GroupStart());
+    if (nb->dd_n_recv > 0) { RCCL_TRY(g_rccl.Send(nb->dd_f_out.p, (size_t)nb->dd_n_recv * 3, ncclFloat, nb->dd_recv_from, nb->dd_comm, st)); }
+    if (nb->dd_n_send > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_f_in.p, (size_t)nb->dd_n_send * 3, ncclFloat, nb->dd_send_to, nb->dd_comm, st)); }
+    RCCL_TRY(g_rccl.GroupEnd());
+    float *entry = nb->dd_shift_index >= 0 ? nb->out + 2 + 3 * nb->dd_shift_index : nullptr;
+    HIP_TRY(nbx_launch_halo_unpack_f(nb->dd_send_slots.p, nb->dd_n_send, nb->dd_f_in.p, nb->f.p, entry, st));
+    return 0;
+}
+
+int nbnxn_hip_dd_sum_outputs(nbnxn_hip_ptr_t nb, int iloc)
+{
+    if (check_dd(nb) || check_loc(iloc)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
+    RCCL_TRY(g_rccl.AllReduce(nb->out, nb->out, (size_t)NBX_OUT_SLOTS * NBX_OUT_STRIDE, ncclFloat, ncclSum, nb->dd_comm, dd_stream(nb, iloc)));
+    return 0;
+}

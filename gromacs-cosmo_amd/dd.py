@@ -113,12 +113,13 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     """Cuts rank `rank`'s slab out of the global system `glob` (every rank holds the synthetic
     global topology; coordinates of imported atoms still arrive by message, as they would in a
     run), grids home and halo zones, and builds both lists."""
-    if world < 2:
-        raise ValueError("domain decomposition needs at least 2 ranks")
+    if world < 1:
+        raise ValueError("domain decomposition needs at least one rank")
     box = np.asarray(glob.box, dtype=np.float32)
     lz = float(box[2]) / world
-    if lz <= ip.rlist:
-        raise ValueError(f"slab thickness {lz:.3f} nm must exceed rlist {ip.rlist:.3f} nm")
+    # one rank is its own neighbour: periodic in z through a halo of its own atoms, which needs room for both
+    if lz <= ip.rlist * (2 if world == 1 else 1):
+        raise ValueError(f"slab thickness {lz:.3f} nm must exceed {'2 x ' if world == 1 else ''}rlist {ip.rlist:.3f} nm")
     z = glob.x[:, 2].astype(np.float64)
     owner = np.clip(np.floor(z / lz).astype(np.int64), 0, world - 1)
     home_ids = np.nonzero(owner == rank)[0]
@@ -160,18 +161,27 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     xq, typ = host.set_atomdata(ntype, glob.type[ids_all], glob.q[ids_all])
     host.copy_x_to_xq(x_all, xq)
 
-    # topology exclusions in local numbering; partners that are not on this rank drop out
-    g2l = np.full(glob.natoms, -1, dtype=np.int64)
-    g2l[ids_all] = np.arange(len(ids_all))
+    # topology exclusions in local numbering; partners that are not on this rank drop out.  A partner maps to every
+    # copy of it that this rank holds: its home atom and / or its halo image (both only when one rank is its own
+    # neighbour; an exclusion between copies that are out of range of each other is never looked at).
+    nloc = len(ids_all)
+    g2l_home = np.full(glob.natoms, -1, dtype=np.int64)
+    g2l_home[home_ids] = np.arange(nhome)
+    g2l_halo = np.full(glob.natoms, -1, dtype=np.int64)
+    g2l_halo[halo_ids] = nhome + np.arange(nhalo)
     cnt = (glob.excl_index[1:] - glob.excl_index[:-1])[ids_all]
     starts = glob.excl_index[:-1][ids_all]
     flat = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
-    partners = g2l[glob.excl_a[flat]]
-    row = np.repeat(np.arange(len(ids_all)), cnt)
+    row = np.repeat(np.arange(nloc), cnt)
+    gp = glob.excl_a[flat]
+    rows = np.concatenate([row, row])
+    partners = np.concatenate([g2l_home[gp], g2l_halo[gp]])
     keep = partners >= 0
-    row, partners = row[keep], partners[keep]
-    excl_index = np.zeros(len(ids_all) + 1, dtype=np.int32)
-    np.add.at(excl_index, row + 1, 1)
+    rows, partners = rows[keep], partners[keep]
+    order = np.lexsort((partners, rows))
+    rows, partners = rows[order], partners[order]
+    excl_index = np.zeros(nloc + 1, dtype=np.int32)
+    np.add.at(excl_index, rows + 1, 1)
     excl_index = np.cumsum(excl_index).astype(np.int32)
     excl_a = partners.astype(np.int32)
 
@@ -265,6 +275,34 @@ class DeviceHalo:
         self.nb.halo_unpack_f(p[0], self.n_send, p[5], self.wrap_shift, abi.NONLOCAL)
 
 
+class RcclHalo:
+    """The same messages issued by the HIP module itself (nbnxn_hip_dd_*): pack kernel, one grouped
+    ncclSend / ncclRecv between devices, unpack kernel, all on the module's non-local stream from ONE call
+    through the C ABI; the slot reduction is the module's ncclAllReduce.  No torch stream is involved, so the
+    step needs no set_stream and no hand-over between torch's collective stream and the module's.  The
+    communicator is the module's own: rank 0 makes the RCCL id, torch.distributed only carries its 128 bytes."""
+
+    def __init__(self, nb, dom, dev):
+        self.nb, self.dom = nb, dom
+        cuda_group = dist.get_backend() != "gloo"
+        idt = torch.zeros(abi.DD_UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev if cuda_group else "cpu")
+        if dom.rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(nb.dd_get_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        nb.dd_init(bytes(idt.cpu().numpy().tobytes()), dom.rank, dom.world)
+        wrap = dom.send_zshift != 0.0
+        self.wrap_shift = 5 * (3 * (1 + 1) + 0 + 1) + 0 + 2 if wrap else -1     # shift (0, 0, +1), as in HaloExchange
+        self.halo_slots = torch.from_numpy(dom.halo_slots.astype(np.int64)).to(dev)
+        nb.dd_set_pulse(dom.down, dom.up, dom.send_slots, dom.halo_slots, (0.0, 0.0, float(dom.send_zshift)) if wrap else None,
+                        self.wrap_shift)
+
+    def send_x(self):
+        self.nb.dd_move_x()
+
+    def return_f(self):
+        self.nb.dd_move_f()
+
+
 def reduce_slots(out_t):
     """Per-step form: the raw accumulation slots summed over ranks in place, ONE collective and no
     arithmetic kernels; fold_slots() turns them into {e_lj, e_el, fshift} when somebody asks."""
@@ -306,7 +344,10 @@ class SlabRun:
     """Weak-scaling workload of bench.py: water_box(tx, ty, tz * world) cut into `world` z slabs."""
 
     def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None, device_search=True,
-                 device_halo=True):
+                 device_halo=True, rccl_direct=False):
+        """device_halo: halo buffers packed by the module's kernels (else torch indexing operations), messages
+        through torch.distributed.  rccl_direct: everything, messages included, issued by the module on its own
+        RCCL communicator (needs one GPU per rank)."""
         from . import gpu
         self.flags = flags
         self.dev = torch.device("cuda", local_rank)
@@ -344,8 +385,11 @@ class SlabRun:
         nb.set_clear_in_kernel(True)
         self._views = {}
         self.f_t, self.out_t = self._current_views()
-        self.device_halo = device_halo
-        self.halo = DeviceHalo(nb, dom, self.dev) if device_halo else HaloExchange(dom, self.xq_t, self.f_t)
+        self.device_halo, self.rccl_direct = device_halo, rccl_direct
+        if rccl_direct:
+            self.halo = RcclHalo(nb, dom, self.dev)
+        else:
+            self.halo = DeviceHalo(nb, dom, self.dev) if device_halo else HaloExchange(dom, self.xq_t, self.f_t)
         self.s_loc = torch.cuda.ExternalStream(nb.stream(abi.LOCAL), device=self.dev)
         self.s_nl = torch.cuda.ExternalStream(nb.stream(abi.NONLOCAL), device=self.dev)
         self.s_default = torch.cuda.default_stream(self.dev)
@@ -373,6 +417,8 @@ class SlabRun:
     def step(self, ev=None):
         nb, fl = self.nb, self.flags
         nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
+        if self.rccl_direct:
+            return self._step_rccl_direct(ev)
         if not self.device_halo:
             return self._step_torch_halo(ev)
         if ev:
@@ -390,6 +436,21 @@ class SlabRun:
         if fl & abi.FORCE_VIRIAL:
             reduce_slots(self._current_views()[1])
         torch.cuda.set_stream(self.s_default)
+
+    def _step_rccl_direct(self, ev=None):
+        """the same step with the module issuing its own RCCL calls: seven calls through the C ABI"""
+        nb, fl = self.nb, self.flags
+        if ev:
+            ev[0].record(self.s_loc)
+        nb.launch_kernel_resident(fl, abi.LOCAL)
+        if ev:
+            ev[1].record(self.s_loc)
+        nb.dd_move_x()                                    # non-local stream: overlaps the local kernel
+        nb.launch_kernel_resident(fl, abi.NONLOCAL)
+        nb.dd_move_f()
+        nb.stream_wait(abi.LOCAL, abi.NONLOCAL)
+        if fl & abi.FORCE_VIRIAL:
+            nb.dd_sum_outputs(abi.LOCAL)
 
     def _step_torch_halo(self, ev=None):
         """the same step with the halo buffers packed by torch indexing operations (HaloExchange)"""

@@ -116,6 +116,13 @@ def load():
     lib.nbnxn_hip_halo_pack_f.argtypes = [vp, vp, ci, vp, ci]
     lib.nbnxn_hip_halo_unpack_f.argtypes = [vp, vp, ci, vp, ci, ci]
     lib.nbnxn_hip_stream_wait.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_dd_get_unique_id.argtypes = [C.c_char_p]
+    lib.nbnxn_hip_dd_init.argtypes = [vp, C.c_char_p, ci, ci]
+    lib.nbnxn_hip_dd_set_pulse.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci]
+    lib.nbnxn_hip_dd_move_x.argtypes = [vp]
+    lib.nbnxn_hip_dd_move_f.argtypes = [vp]
+    lib.nbnxn_hip_dd_sum_outputs.argtypes = [vp, ci]
+    lib.nbnxn_hip_dd_finish.argtypes = [vp]
     lib.nbnxn_hip_get_output_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
     lib.nbnxn_hip_set_timing.argtypes = [vp, ci]
     lib.nbnxn_hip_set_clear_in_kernel.argtypes = [vp, ci]
@@ -392,6 +399,34 @@ class NbnxnHip:
 
     def stream_wait(self, iloc_waits, iloc_done):
         self._chk(self.lib.nbnxn_hip_stream_wait(self.h, iloc_waits, iloc_done))
+
+    # ---- domain decomposition over RCCL, issued by the library (nbnxn_hip_dd_*) ----
+    def dd_get_unique_id(self):
+        buf = C.create_string_buffer(abi.DD_UNIQUE_ID_BYTES)
+        self._chk(self.lib.nbnxn_hip_dd_get_unique_id(buf))
+        return buf.raw
+
+    def dd_init(self, unique_id, rank, nranks):
+        assert len(unique_id) == abi.DD_UNIQUE_ID_BYTES
+        self._chk(self.lib.nbnxn_hip_dd_init(self.h, unique_id, rank, nranks))
+
+    def dd_set_pulse(self, send_to, recv_from, send_slots, recv_slots, shift=None, shift_index=-1):
+        ss = np.ascontiguousarray(send_slots, dtype=np.int32)
+        rs = np.ascontiguousarray(recv_slots, dtype=np.int32)
+        sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+        self._chk(self.lib.nbnxn_hip_dd_set_pulse(self.h, send_to, recv_from, abi.ptr(ss), len(ss), abi.ptr(rs), len(rs), abi.ptr(sh), shift_index))
+
+    def dd_move_x(self):
+        self._chk(self.lib.nbnxn_hip_dd_move_x(self.h))
+
+    def dd_move_f(self):
+        self._chk(self.lib.nbnxn_hip_dd_move_f(self.h))
+
+    def dd_sum_outputs(self, iloc=abi.LOCAL):
+        self._chk(self.lib.nbnxn_hip_dd_sum_outputs(self.h, iloc))
+
+    def dd_finish(self):
+        self._chk(self.lib.nbnxn_hip_dd_finish(self.h))
 
     def set_clear_in_kernel(self, on):
         self._chk(self.lib.nbnxn_hip_set_clear_in_kernel(self.h, int(on)))

@@ -584,6 +584,38 @@ int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const
  * iloc_done holds now (two pre-made events, no allocation); a no-op on one-stream handles */
 int nbnxn_hip_stream_wait(nbnxn_hip_ptr_t nb, int iloc_waits, int iloc_done);
 
+/* ------------------------------------------------------------------------------------
+ * Domain decomposition over RCCL: the halo exchange of one decomposed dimension,
+ * issued by this library on its own streams.  These calls stand where the reference has
+ * dd_move_x (sim_util.c:1114; mdlib/domdec.c:651-758) and dd_move_f (sim_util.c:1428;
+ * domdec.c:761-875), whose MPI_Sendrecv of host buffers (dd_sendrecv_rvec,
+ * domdec_network.c:114) becomes pack kernel -> one grouped ncclSend / ncclRecv between devices ->
+ * unpack kernel on the non-local stream; energies and shift forces are summed over ranks by one
+ * ncclAllReduce of the accumulation slots (the reference sums them on the host in global_stat).
+ * One pulse along one dimension (the slab decomposition of gromacs-cosmo_amd/dd.py).  RCCL is bound
+ * at run time: the copy the process already holds (librccl.so.1), else the system's.
+ * ---------------------------------------------------------------------------------- */
+#define NBX_DD_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: one rank makes the id, the host's launcher hands it to the others (mdrun:
+ * MPI_Bcast over cr->mpi_comm_mysim; the Python mirror: torch.distributed.broadcast) */
+int nbnxn_hip_dd_get_unique_id(char *id128);
+/* ncclCommInitRank on the handle's device: collective over the nranks ranks of the id */
+int nbnxn_hip_dd_init(nbnxn_hip_ptr_t nb, const char *id128, int rank, int nranks);
+/* Per search: coordinates of the grid slots send_slots go to rank send_to (plus shift, the box
+ * vector of a pulse across a periodic boundary, NULL = none), coordinates for the slots recv_slots
+ * arrive from rank recv_from; forces travel the reverse way, and those that arrive add to the shift
+ * force shift_index as well (-1: not).  Host arrays; copied. */
+int nbnxn_hip_dd_set_pulse(nbnxn_hip_ptr_t nb, int send_to, int recv_from, const int *send_slots, int n_send,
+                           const int *recv_slots, int n_recv, const float *shift, int shift_index);
+/* dd_move_x / dd_move_f for that pulse, asynchronous on the non-local stream; every rank calls them */
+int nbnxn_hip_dd_move_x(nbnxn_hip_ptr_t nb);
+int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb);
+/* in-place ncclAllReduce(sum) of the output slots in use, on the stream of iloc (order it after both
+ * kernels with nbnxn_hip_stream_wait) */
+int nbnxn_hip_dd_sum_outputs(nbnxn_hip_ptr_t nb, int iloc);
+/* destroys the communicator and the halo buffers (nbnxn_hip_free does it too) */
+int nbnxn_hip_dd_finish(nbnxn_hip_ptr_t nb);
+
 /* reads the (possibly pruned) cj4 array back from HBM; for tests of the prune flavour. */
 int nbnxn_hip_download_cj4(nbnxn_hip_ptr_t nb, int iloc, int ncj4, nbx_cj4_t *cj4);
 

@@ -85,7 +85,9 @@ def _worker(rank, world, port, model, min_ci_balanced, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,model,mcb", [(2, "spc", 0), (2, "spce", 200), (3, "spc", 0)])
+# world 1: one rank that is its own neighbour (periodic in z through a halo of its own atoms): the form in which a
+# one-GPU box can run the whole decomposed step over RCCL (tests/test_gpu_z_dd.py)
+@pytest.mark.parametrize("world,model,mcb", [(2, "spc", 0), (2, "spce", 200), (3, "spc", 0), (1, "spce", 0)])
 def test_slab_decomposition_matches_single_domain(world, model, mcb):
     with mp.Manager() as m:
         ret = m.dict()

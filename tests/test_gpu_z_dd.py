@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 DEADLINE_S = 100
 
 
-def _worker(rank, world, port, model, device_halo, ret):
+def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_direct=False):
     import datetime
     import faulthandler
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -37,13 +37,14 @@ def _worker(rank, world, port, model, device_halo, ret):
     from gromacs_cosmo_amd import abi, dd
     import oracle as O
     from util import virial_from
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
-                            timeout=datetime.timedelta(seconds=60))
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60), **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
     try:
-        torch.cuda.set_device(0)
         ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
         tiles = (2, 2, 2)
-        run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo)
+        run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
+                         rccl_direct=rccl_direct)
         dom = run.dom
         # wreck the imported coordinates on the device: the step has to bring them back
         run.xq_t[run.halo.halo_slots, :3] = 1e6
@@ -60,7 +61,10 @@ def _worker(rank, world, port, model, device_halo, ret):
         # virial: home atoms' x (x) f summed over ranks, plus the shift-force term, which includes the forces
         # that came back across the periodic wrap (dd_move_f, domdec.c:837-851)
         xf_t = torch.from_numpy(glob.x[dom.home_ids].astype(np.float64).T @ f_home.astype(np.float64))
+        if backend == "nccl":
+            xf_t = xf_t.cuda()
         dist.all_reduce(xf_t)
+        xf_t = xf_t.cpu()
         vir_dd = -0.5 * (xf_t.numpy() + dom.shift_vec.astype(np.float64).T @ e[2:2 + 135].reshape(45, 3))
         vir_ref = virial_from(np.concatenate([glob.x, np.zeros((glob.natoms, 1), np.float32)], 1), f_ref,
                               prep.shift_vec, np.asarray(o["fshift"]))
@@ -98,6 +102,23 @@ def test_slabrun_two_ranks_one_gpu(model, device_halo):
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
         assert r["vir_err"] < 1e-5, r
+
+
+@pytest.mark.parametrize("model,rccl_direct", [("spce", True), ("spc", True), ("spce", False)])
+def test_slabrun_one_rank_over_rccl(model, rccl_direct):
+    """The whole decomposed step over the RCCL backend on the one GPU of the box: ONE rank that is its own neighbour
+    (periodic in z through a halo of its own atoms), so every message is a real RCCL send / receive (to itself) and the
+    reduction a real all-reduce.  rccl_direct: issued by the HIP module (nbnxn_hip_dd_*, what bench.py --gpus N uses);
+    otherwise through torch.distributed (all_to_all_single).  Forces, energies and virial against the single-domain
+    oracle."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_worker, args=(1, _free_port(), model, True, ret, "nccl", rccl_direct), nprocs=1, join=False))
+        r = ret[0]
+    assert r["err"] < 1e-5, r
+    assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
+    assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
+    assert r["vir_err"] < 1e-5, r
 
 
 def _rccl_worker(rank, port, ret):
@@ -144,3 +165,91 @@ def test_exchange_over_rccl_single_rank():
         ret = m.dict()
         _watch(mp.spawn(_rccl_worker, args=(_free_port(), ret), nprocs=1, join=False))
         assert ret["ok"]
+
+
+def _rccl_direct_worker(rank, port, ret):
+    """one rank: the module's own RCCL path (nbnxn_hip_dd_*) sending to itself"""
+    import faulthandler
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    hang_log = open(os.path.join(ROOT, "gpurun_out", "dd_hang_rccl_direct.txt"), "w")
+    faulthandler.dump_traceback_later(DEADLINE_S - 20, file=hang_log, exit=False)
+    import gromacs_cosmo_amd as g
+    from gromacs_cosmo_amd import abi
+    from gromacs_cosmo_amd.dd import _DevArray
+    torch.cuda.set_device(0)
+    try:
+        s = g.system.water_box(2, 2, 2, model="spc")
+        ip = g.system.reaction_field(0.9)
+        p = g.workload.prepare(s, ip, 0)
+        nb = g.gpu.NbnxnHip(0, local_and_nonlocal=True)
+        fresh = g.gpu.NbnxnHip(0)
+        refused = 0
+        for call in (fresh.dd_move_x, lambda: fresh.dd_sum_outputs(abi.LOCAL)):      # no communicator yet
+            try:
+                call()
+            except g.gpu.HipError:
+                refused += 1
+        fresh.close()
+        g.workload.upload(nb, p, ip)
+        nb.upload_xq(p.xq)
+        nb.dd_init(nb.dd_get_unique_id(), 0, 1)
+        try:
+            nb.dd_move_x()                                                          # no pulse yet
+        except g.gpu.HipError:
+            refused += 1
+        try:
+            nb.dd_set_pulse(1, 0, [1, 2], [3, 4])                                   # neighbour outside the communicator
+        except g.gpu.HipError:
+            refused += 1
+        rng = np.random.default_rng(9)
+        perm = rng.permutation(p.natoms)
+        send, recv = perm[:500].astype(np.int32), perm[500:1100].astype(np.int32)[:500]
+        shift = np.array([0.1, 0.2, 3.0], dtype=np.float32)
+        nb.dd_set_pulse(0, 0, send, recv, shift, 17)
+        nb.clear_outputs(abi.FORCE_VIRIAL)
+        nb.wait_gpu(0)
+        d_xq, d_f, _ = nb.device_buffers()
+        d_out, nslots, stride = nb.output_slots()
+        xq_t = torch.as_tensor(_DevArray(d_xq, (p.natoms, 4)), device="cuda:0")
+        f_t = torch.as_tensor(_DevArray(d_f, (p.natoms, 3)), device="cuda:0")
+        out_t = torch.as_tensor(_DevArray(d_out, (nslots * stride,)), device="cuda:0")
+        ok = True
+        for _ in range(2):
+            nb.dd_move_x()
+        torch.cuda.synchronize()
+        want = p.xq.copy()
+        want[recv, :3] = p.xq[send, :3] + shift
+        want[recv, 3] = p.xq[send, 3]
+        ok = ok and np.array_equal(xq_t.cpu().numpy(), want)
+        f0 = rng.normal(0, 300, (p.natoms, 3)).astype(np.float32)
+        f_t.copy_(torch.from_numpy(f0))
+        torch.cuda.synchronize()
+        nb.dd_move_f()
+        nb.stream_wait(abi.LOCAL, abi.NONLOCAL)
+        nb.dd_sum_outputs(abi.LOCAL)
+        torch.cuda.synchronize()
+        wantf = f0.copy()
+        wantf[send] += f0[recv]
+        ok = ok and np.array_equal(f_t.cpu().numpy(), wantf)
+        o = out_t.cpu().numpy()
+        got = o[2 + 3 * 17:5 + 3 * 17].astype(np.float64)
+        ok = ok and np.abs(got - f0[recv].astype(np.float64).sum(0)).max() < 1e-6 * np.abs(f0[recv]).sum()
+        o[2 + 3 * 17:5 + 3 * 17] = 0
+        ok = ok and not o.any()
+        nb.close()
+        ret["ok"], ret["refused"] = bool(ok), refused
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+        hang_log.close()
+        if os.path.getsize(hang_log.name) == 0:
+            os.remove(hang_log.name)
+
+
+def test_module_rccl_path_single_rank():
+    """nbnxn_hip_dd_*: communicator from a unique id, pack -> grouped ncclSend/ncclRecv -> unpack on the module's
+    stream, reverse path with the shift-force term, ncclAllReduce of the slots; one rank talking to itself is what a
+    one-GPU box can show."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_rccl_direct_worker, args=(_free_port(), ret), nprocs=1, join=False))
+        assert ret["ok"] and ret["refused"] == 4

@@ -47,4 +47,26 @@ t("event record+wait pair", evsync)
 def a2a_async():
     w = dist.all_to_all_single(r, s, output_split_sizes=[12000], input_split_sizes=[12000], async_op=True)
 t("all_to_all_single async", a2a_async)
+# the module's own RCCL path (nbnxn_hip_dd_*), one rank talking to itself
+import sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gromacs_cosmo_amd as g
+from gromacs_cosmo_amd import abi
+sysm = g.system.water_box(5, 5, 6, model="spce")
+ip = g.system.ewald(1.0)
+p = g.workload.prepare(sysm, ip, 0)
+nb = g.gpu.NbnxnHip(0, local_and_nonlocal=True)
+nb.set_timing(False)
+g.workload.upload(nb, p, ip)
+nb.upload_xq(p.xq)
+nb.dd_init(nb.dd_get_unique_id(), 0, 1)
+perm = np.random.default_rng(1).permutation(p.natoms)
+nb.dd_set_pulse(0, 0, perm[:8575], perm[8575:17150], (0, 0, 1.0), 17)
+nb.clear_outputs(abi.FORCE_VIRIAL)
+nb.wait_gpu(0)
+t("module dd_move_x (8575 atoms)", nb.dd_move_x)
+t("module dd_move_f", nb.dd_move_f)
+t("module dd_sum_outputs", lambda: nb.dd_sum_outputs(abi.LOCAL))
+nb.close()
 dist.destroy_process_group()
