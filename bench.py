@@ -316,8 +316,11 @@ def main():
             out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
             out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if decomposed:
+        sync()
+        dist.barrier()
+        run.nb.close()               # also destroys the module's RCCL communicator, on every rank
         dist.destroy_process_group()
 
 
