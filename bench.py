@@ -279,7 +279,7 @@ def main():
     # figure measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command is kept
     # under profiles/ and quoted only when the workload is the one it was measured on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_c_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r1_i_hbm_traffic.json")
     if not decomposed and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
             and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
@@ -304,7 +304,7 @@ def main():
                             "flops_per_pair": flops_pair}, **cfg_extra),
             "roofline": {"bound": "fp32-vector", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from profiles/r1_c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+                         "traffic_note": "HBM bytes per launch from profiles/r1_i_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                          "kernel_ms": kernel_ms, "kernel_ms_events_raw": kernel_ms_raw, "event_pair_ms": event_pair_ms,
                          "note": "algorithmic flops = pair slots x nrnb.c cost (gmxlib/nrnb.c:101-106); duration = mean HIP-event time around the nonbonded kernel launch inside the timed region minus the latency of an empty event pair"},
         }
