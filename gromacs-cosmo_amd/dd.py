@@ -448,8 +448,10 @@ class SlabRun:
         nb.dd_move_x()                                    # non-local stream: overlaps the local kernel
         nb.launch_kernel_resident(fl, abi.NONLOCAL)
         nb.dd_move_f()
-        nb.stream_wait(abi.LOCAL, abi.NONLOCAL)
+        nb.stream_wait(abi.LOCAL, abi.NONLOCAL)           # ONE cross-stream wait: what follows on the local stream sees all of it
         if fl & abi.FORCE_VIRIAL:
+            # on the local stream, so that the next step's coordinate exchange (non-local stream) need not wait for it;
+            # every rank issues its RCCL calls in the same order, and RCCL runs one communicator's kernels in launch order
             nb.dd_sum_outputs(abi.LOCAL)
 
     def _step_torch_halo(self, ev=None):
