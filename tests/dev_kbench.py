@@ -1,7 +1,8 @@
 """Kernel A/B bench: times the resident kernel for RF-F and Ewald-VF on the 97k box and
-checks parity against the oracle.  usage: python tools/kbench.py [variant ...]"""
+checks parity against the oracle (which is why it lives under tests/: only tests, smoke() and
+bench.py's CPU baseline touch oracle/).  Not collected by pytest.  usage: python tests/dev_kbench.py [variant ...]"""
 import sys, os
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gromacs_cosmo_amd as g
 from gromacs_cosmo_amd import abi
