@@ -33,7 +33,8 @@ from .host import NbnxnHost, PairList
 class Domain:
     rank: int
     world: int
-    box: np.ndarray            # global box
+    box: np.ndarray            # global box (its diagonal)
+    box_search: np.ndarray     # the box as the search takes it: [3], or the [3, 3] matrix of a cell skewed in xy
     lz: float                  # slab thickness
     nhome: int                 # home atoms (caller order: home first, halo after)
     nhalo: int
@@ -115,7 +116,15 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     run), grids home and halo zones, and builds both lists."""
     if world < 1:
         raise ValueError("domain decomposition needs at least one rank")
-    box = np.asarray(glob.box, dtype=np.float32)
+    # a triclinic cell may be decomposed along z as long as box[ZZ] lies along z (the halo shift is then the plain
+    # z translation these messages apply); box[YY][XX] may be skewed, the search handles it through its x/y shifts
+    box_search = np.asarray(glob.box, dtype=np.float32)
+    if box_search.shape == (3, 3):
+        if box_search[2, 0] != 0 or box_search[2, 1] != 0:
+            raise ValueError("slab decomposition along z needs box[ZZ] along z")
+        box = np.ascontiguousarray(np.diag(box_search))
+    else:
+        box = box_search
     lz = float(box[2]) / world
     # one rank is its own neighbour: periodic in z through a halo of its own atoms, which needs room for both
     if lz <= ip.rlist * (2 if world == 1 else 1):
@@ -148,7 +157,7 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     x_halo = x_recv.cpu().numpy()
 
     # grids: zone 0 = home slab, zone 1 = the rlist-thick layer above it
-    host = NbnxnHost(box, pbc_shift_dim=(1, 1, 0))
+    host = NbnxnHost(box_search, pbc_shift_dim=(1, 1, 0))
     z0 = rank * lz
     zones = [((0.0, 0.0, z0), (float(box[0]), float(box[1]), z0 + lz), 0, nhome)]
     host.put_on_grid(0, zones[0][0], zones[0][1], 0, x_home)
@@ -188,7 +197,7 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     pl_local = host.make_pairlist(abi.LOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
     pl_nonlocal = host.make_pairlist(abi.NONLOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
     cell = host.cell_index()
-    return Domain(rank=rank, world=world, box=box, lz=lz, nhome=nhome, nhalo=nhalo, home_ids=home_ids,
+    return Domain(rank=rank, world=world, box=box, box_search=box_search, lz=lz, nhome=nhome, nhalo=nhalo, home_ids=home_ids,
                   halo_ids=halo_ids, host=host, xq=xq, type=typ, ntype=ntype, nbfp=glob.nbfp(),
                   shift_vec=host.shift_vec(), pl_local=pl_local, pl_nonlocal=pl_nonlocal,
                   npad=len(xq), npad_local=host.natoms_padded_local,
@@ -360,7 +369,7 @@ class SlabRun:
         if device_search:
             # grids and both lists made on the device; the host-side builder's results, which the
             # halo bookkeeping above came from, double as the check that both see the same grid
-            npad = nb.put_on_grid_zones(dom.box, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=(1, 1, 0))
+            npad = nb.put_on_grid_zones(dom.box_search, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=(1, 1, 0))
             assert npad == dom.npad
             nb.make_pairlist(dom.rlist, dom.excl_index, dom.excl_a, dom.min_ci_balanced, iloc=abi.LOCAL)
             if len(dom.zones) > 1:

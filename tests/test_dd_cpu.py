@@ -35,8 +35,12 @@ def _worker(rank, world, port, model, min_ci_balanced, ret):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
-        glob = g.system.water_box(2, 2, 2 * world, model=model)
+        ip = g.system.reaction_field(0.9) if model in ("spc", "chains_xy") else g.system.ewald(0.9)
+        if model == "chains_xy":
+            # a cell skewed in the xy plane (box[YY][XX] != 0), box[ZZ] along z: decomposable along z
+            glob = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, 0, 0))
+        else:
+            glob = g.system.water_box(2, 2, 2 * world, model=model)
         dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced)
         xq_t = torch.from_numpy(dom.xq)                 # aliases dom.xq
         f_t = torch.zeros((dom.npad, 3), dtype=torch.float64)
@@ -87,7 +91,7 @@ def _worker(rank, world, port, model, min_ci_balanced, ret):
 
 # world 1: one rank that is its own neighbour (periodic in z through a halo of its own atoms): the form in which a
 # one-GPU box can run the whole decomposed step over RCCL (tests/test_gpu_z_dd.py)
-@pytest.mark.parametrize("world,model,mcb", [(2, "spc", 0), (2, "spce", 200), (3, "spc", 0), (1, "spce", 0)])
+@pytest.mark.parametrize("world,model,mcb", [(2, "spc", 0), (2, "spce", 200), (3, "spc", 0), (1, "spce", 0), (2, "chains_xy", 0)])
 def test_slab_decomposition_matches_single_domain(world, model, mcb):
     with mp.Manager() as m:
         ret = m.dict()
@@ -102,3 +106,11 @@ def test_slab_decomposition_matches_single_domain(world, model, mcb):
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r
         assert r["vir_err"] < 1e-5, r
+
+
+def test_decomposition_across_a_skewed_box_vector_is_refused():
+    import gromacs_cosmo_amd as g
+    from gromacs_cosmo_amd import dd
+    glob = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, -5, 4))
+    with pytest.raises(ValueError):
+        dd.build_domain(glob, g.system.reaction_field(0.9), 0, 2, torch.device("cpu"))

@@ -320,7 +320,8 @@ def test_verlet_loop_with_dynamic_pruning(nb):
 def _slab_domain(glob, rank, world, rlist):
     """the arrays dd.build_domain would hand to the grid for rank `rank` of `world` z-slabs (no messages needed here:
     every rank of a test holds the global system)"""
-    box = np.asarray(glob.box, dtype=np.float32)
+    box_search = np.asarray(glob.box, dtype=np.float32)      # [3], or the matrix of a cell skewed in xy
+    box = np.ascontiguousarray(np.diag(box_search)) if box_search.shape == (3, 3) else box_search
     lz = float(box[2]) / world
     owner = np.clip(np.floor(glob.x[:, 2].astype(np.float64) / lz).astype(np.int64), 0, world - 1)
     home = np.nonzero(owner == rank)[0]
@@ -344,17 +345,20 @@ def _slab_domain(glob, rank, world, rlist):
         part = g2l[glob.excl_a[glob.excl_index[a]:glob.excl_index[a + 1]]]
         ea.extend(int(v) for v in part if v >= 0)
         ei.append(len(ea))
-    return box, ids, x_all, zones, np.array(ei, dtype=np.int32), np.array(ea, dtype=np.int32)
+    return box_search, ids, x_all, zones, np.array(ei, dtype=np.int32), np.array(ea, dtype=np.int32)
 
 
-@pytest.mark.parametrize("kind,rank", [("water", 0), ("water", 1), ("chains", 1)])
+@pytest.mark.parametrize("kind,rank", [("water", 0), ("water", 1), ("chains", 1), ("chains skewed in xy", 0), ("chains skewed in xy", 1)])
 def test_device_search_with_a_halo_zone(nb, kind, rank):
     """home zone + one halo zone (a z-slab decomposition's rank, the upper one wrapping around the box): both grids,
     the local and the non-local list equal to the host builder's; forces of both kernels against the oracle"""
     if kind == "water":
         glob, ip = g.system.water_box(2, 2, 4, model="spce"), g.system.ewald(0.9)
-    else:
+    elif kind == "chains":
         glob, ip = g.system.lj_chain_mixture(6000, ntype=8, seed=21), g.system.reaction_field(0.9, rlist=1.0)
+    else:
+        # box[YY][XX] != 0 with box[ZZ] along z: what a z-slab decomposition can take (dd.build_domain)
+        glob, ip = g.system.lj_chain_mixture(5832, ntype=8, seed=21, skew=(7, 0, 0)), g.system.reaction_field(0.9, rlist=1.0)
     box, ids, x_all, zones, ei, ea = _slab_domain(glob, rank, 2, ip.rlist)
     mcb = 150
     h = g.host.NbnxnHost(box, (1, 1, 0))
