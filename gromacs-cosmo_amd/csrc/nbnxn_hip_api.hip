@@ -1316,6 +1316,7 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
 int nbnxn_hip_set_progressive_balance(nbnxn_hip_ptr_t nb, int on)
 {
     if (check_handle(nb)) { return 1; }
+    HIP_TRY(hipSetDevice(nb->device));
     if (!nb->search) { nb->search = nbx_search_create(); }
     nbx_search_set_progressive_balance(nb->search, on != 0);
     return 0;

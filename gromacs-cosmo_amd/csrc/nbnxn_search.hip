@@ -765,12 +765,59 @@ __global__ void k_split(int nentries, EntryMap em, const int *__restrict__ ncj, 
     if (!WRITE) { nparts[e] = count; }
 }
 
-// sort_sci key: entries with more cj4 groups first, counts clipped at m
+// sort_sci (nbnxn_search.c:5517-5580) is a stable counting sort on a small key: entries with more cj4 groups first,
+// counts clipped at m, m + 1 <= 64 keys.  One wave per 64 consecutive entries.  COUNT: hist[key][wave] = how many of
+// the wave's entries have that key (key-major, so that ONE exclusive scan over the array gives every (key, wave) its
+// first output position).  Otherwise: an entry goes to that position plus its rank among the wave's earlier entries
+// with the same key.  For the few tens of thousands of entries of a list this replaces a library sort of ~60 us
+// (five merge passes) by two short kernels and a scan.
+__device__ __forceinline__ int sci_sort_key(const nbx_sci_t &e, int m) { return m - min(m, e.cj4_ind_end - e.cj4_ind_start); }
+
+// the same key for the library sort that takes over when m + 1 > 64
 __global__ void k_sort_keys(int nsci, const nbx_sci_t *__restrict__ sci, int m, unsigned *__restrict__ key)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsci) { return; }
-    key[i] = (unsigned)(m - min(m, sci[i].cj4_ind_end - sci[i].cj4_ind_start));
+    key[i] = (unsigned)sci_sort_key(sci[i], m);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+k_sort_sci(int nsci, int nwaves, int m, const nbx_sci_t *__restrict__ sci, int *__restrict__ hist, const int *__restrict__ first,
+           nbx_sci_t *__restrict__ sci_out)
+{
+    const int  w    = blockIdx.x;
+    const int  lane = threadIdx.x;
+    const int  i    = w * 64 + lane;
+    const bool have = i < nsci;
+    nbx_sci_t  e;
+    if (have) { e = sci[i]; }
+    const int key = have ? sci_sort_key(e, m) : -1;
+    if (COUNT)
+    {
+        // lane k counts key k
+        int mine = 0;
+        for (int k = 0; k <= m; k++)
+        {
+            const unsigned long long b = __ballot(key == k);
+            if (lane == k) { mine = __popcll(b); }
+        }
+        if (lane <= m) { hist[(size_t)lane * nwaves + w] = mine; }
+    }
+    else
+    {
+        unsigned long long same = 0;
+        for (int k = 0; k <= m; k++)
+        {
+            const unsigned long long b = __ballot(key == k);
+            if (key == k) { same = b; }
+        }
+        if (have)
+        {
+            const int rank = __popcll(same & ((1ull << lane) - 1ull));
+            sci_out[first[(size_t)key * nwaves + w] + rank] = e;
+        }
+    }
 }
 
 inline int blocks_for(size_t n, int bs) { return (int)((n + bs - 1) / bs); }
@@ -811,10 +858,19 @@ struct nbx_search {
     Buf<nbx_excl_t> excl;
     Buf<nbx_sci_t>  sci_a, sci_b;
     Buf<unsigned>   skey_in, skey_out;
+    Buf<int>        sort_hist, sort_first;
     nbx_prim_tmp    tmp;
+    // pinned landing area for the handful of integers the host needs (array sizes): a device-to-host copy into
+    // pageable memory is staged and costs ~25 us each, into pinned memory a third of that
+    int            *h_pin = nullptr;
 };
 
-nbx_search *nbx_search_create() { return new nbx_search(); }
+nbx_search *nbx_search_create()
+{
+    nbx_search *s = new nbx_search();
+    if (hipHostMalloc((void **)&s->h_pin, 16 * sizeof(int), hipHostMallocPortable) != hipSuccess) { s->h_pin = nullptr; }
+    return s;
+}
 
 void nbx_search_destroy(nbx_search *s)
 {
@@ -824,8 +880,9 @@ void nbx_search_destroy(nbx_search *s)
     s->bb.release(); s->bbcz.release(); s->bbsc.release(); s->zrange.release();
     s->ncj.release(); s->ncj4_e.release(); s->cj4_start.release(); s->need_excl.release(); s->excl_rank.release();
     s->nparts.release(); s->part_start.release(); s->cj4.release(); s->excl.release(); s->sci_a.release(); s->sci_b.release();
-    s->skey_in.release(); s->skey_out.release();
+    s->skey_in.release(); s->skey_out.release(); s->sort_hist.release(); s->sort_first.release();
     nbx_prim_free(s->tmp);
+    if (s->h_pin) { (void)hipHostFree(s->h_pin); }
     delete s;
 }
 
@@ -910,8 +967,10 @@ int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float
     S_TRY(nbx_prim_exclusive_sum(s->tmp, z.ncz.p, z.cxy_ind.p, ncxy + 1, st));
     S_TRY(nbx_prim_exclusive_sum(s->tmp, z.cxy_na.p, z.atom_start.p, ncxy + 1, st));
     int nc = 0;
-    S_TRY(hipMemcpyAsync(&nc, z.cxy_ind.p + ncxy, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!s->h_pin) { return sfail("no pinned host memory for the search"); }
+    S_TRY(hipMemcpyAsync(&s->h_pin[0], z.cxy_ind.p + ncxy, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
+    nc = s->h_pin[0];
     z.nc    = nc;
     z.cell0 = s->nc;
     s->nc += nc;
@@ -1056,9 +1115,11 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     S_TRY(hipGetLastError());
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncj4_e.p, s->cj4_start.p, nent + 1, st));
     int h1[2] = {0, 0};
-    S_TRY(hipMemcpyAsync(&h1[0], s->cj4_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
-    S_TRY(hipMemcpyAsync(&h1[1], cnt + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!s->h_pin) { return sfail("no pinned host memory for the search"); }
+    S_TRY(hipMemcpyAsync(&s->h_pin[1], s->cj4_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&s->h_pin[2], cnt + 2, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
+    h1[0] = s->h_pin[1]; h1[1] = s->h_pin[2];
     const int ncj4  = h1[0];
     s->nsubc_tot0   = h1[1];
     const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced, same ? 1.0 : 0.25);
@@ -1076,10 +1137,11 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->need_excl.p, s->excl_rank.p, 2 * ncj4 + 1, st));
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->nparts.p, s->part_start.p, nent + 1, st));
     int h2[3] = {0, 0, 0};
-    S_TRY(hipMemcpyAsync(&h2[0], s->excl_rank.p + 2 * ncj4, sizeof(int), hipMemcpyDeviceToHost, st));
-    S_TRY(hipMemcpyAsync(&h2[1], s->part_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
-    S_TRY(hipMemcpyAsync(&h2[2], cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&s->h_pin[3], s->excl_rank.p + 2 * ncj4, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&s->h_pin[4], s->part_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&s->h_pin[5], cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
+    h2[0] = s->h_pin[3]; h2[1] = s->h_pin[4]; h2[2] = s->h_pin[5];
     const int nexcl = 1 + h2[0], nsci = h2[1], nci_tot = h2[2];
 
     if (s->excl.reserve(nexcl) || s->sci_a.reserve((size_t)nsci + 1) || s->sci_b.reserve((size_t)nsci + 1) || s->skey_in.reserve((size_t)nsci + 1)
@@ -1096,11 +1158,27 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     if (ncj4 > nsci && nsci > 0)
     {
         const int m = (int)(2 * (size_t)ncj4 / (size_t)nsci);
-        int       bits = 1;
-        while ((1 << bits) <= m) { bits++; }
-        hipLaunchKernelGGL(k_sort_keys, dim3(blocks_for(nsci, 256)), dim3(256), 0, st, nsci, s->sci_a.p, m, s->skey_in.p);
-        S_TRY(hipGetLastError());
-        S_TRY(nbx_prim_sort_u32_sci(s->tmp, s->skey_in.p, s->skey_out.p, s->sci_a.p, s->sci_b.p, nsci, bits, st));
+        if (m + 1 <= 64)
+        {
+            const int    nwaves = (nsci + 63) / 64;
+            const size_t nh     = (size_t)(m + 1) * nwaves;
+            if (s->sort_hist.reserve(nh + 1) || s->sort_first.reserve(nh + 1)) { return 1; }
+            hipLaunchKernelGGL((k_sort_sci<true>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, s->sci_a.p, s->sort_hist.p, (const int *)nullptr,
+                               (nbx_sci_t *)nullptr);
+            S_TRY(hipGetLastError());
+            S_TRY(nbx_prim_exclusive_sum(s->tmp, s->sort_hist.p, s->sort_first.p, (int)nh, st));
+            hipLaunchKernelGGL((k_sort_sci<false>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, s->sci_a.p, (int *)nullptr, s->sort_first.p,
+                               s->sci_b.p);
+            S_TRY(hipGetLastError());
+        }
+        else
+        {
+            int bits = 1;
+            while ((1 << bits) <= m) { bits++; }
+            hipLaunchKernelGGL(k_sort_keys, dim3(blocks_for(nsci, 256)), dim3(256), 0, st, nsci, s->sci_a.p, m, s->skey_in.p);
+            S_TRY(hipGetLastError());
+            S_TRY(nbx_prim_sort_u32_sci(s->tmp, s->skey_in.p, s->skey_out.p, s->sci_a.p, s->sci_b.p, nsci, bits, st));
+        }
         sci_final = s->sci_b.p;
     }
     out->nsci = nsci; out->ncj4 = ncj4; out->nexcl = nexcl; out->nci_tot = nci_tot;
