@@ -95,6 +95,7 @@ struct ListParams {
     float      box[3];    // the diagonal
     float      byx, bzx, bzy;   // box[YY][XX], box[ZZ][XX], box[ZZ][YY] of a triclinic box
     int        shp[3];
+    int        tmp_cap;   // MODE 2 of k_list: scratch slots per entry
     float      rlist, rl2;
     ZoneParams zp[MAX_ZONES];
 };
@@ -393,18 +394,25 @@ __device__ __forceinline__ float bb_dist2(const float *a, const float *b)
     return d2;
 }
 
-// One wave per entry e = (i super-cell) * 14 + (shift slot).  FILL = false: ncj[e] = number of
-// j-clusters the entry keeps.  FILL = true: the cj4 groups of the entry are written at
-// cj4_start[e] (the array was zeroed), the groups holding the entry's own clusters are marked
-// as needing exclusion words, and the cluster pairs are counted into nci_tot.
-template <bool FILL>
+// One wave per entry e = (i super-cell) * 14 + (shift slot).
+// MODE 2 (the usual route): ONE walk.  ncj[e] = number of j-clusters the entry keeps; the j-clusters and their
+//   i-masks go to the entry's own range of a scratch array (LIST_TMP_CAP slots per entry), the cluster pairs are
+//   counted into nci_tot; k_list_compact then packs the ranges into cj4 groups once the scan has placed them.
+//   An entry with more j-clusters than its range raises `overflow`, and the list is made the two-walk way:
+// MODE 0: only ncj[e].  MODE 1: the cj4 groups of the entry are written at cj4_start[e] (the array was zeroed), the
+//   groups holding the entry's own clusters are marked as needing exclusion words, cluster pairs counted.
+constexpr int LIST_TMP_CAP = 512;   // default of nbx_search::list_cap (GMX_HIP_NB_LIST_TMP_CAP overrides it: tests of the other route)
+
+template <int MODE>
 __global__ void __launch_bounds__(64)
 k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb,
        const float *__restrict__ bbcz, const float *__restrict__ bbsc, const unsigned *__restrict__ zrange,
        const float4 *__restrict__ xq, int *__restrict__ ncj,
        const int *__restrict__ cj4_start, nbx_cj4_t *__restrict__ cj4, int *__restrict__ need_excl,
-       unsigned *__restrict__ nci_tot)
+       unsigned *__restrict__ nci_tot, int *__restrict__ tmp_cj, unsigned char *__restrict__ tmp_mb, int *__restrict__ overflow)
 {
+    constexpr bool FILL = (MODE == 1);
+    constexpr bool TEMP = (MODE == 2);
     const int e    = blockIdx.x;
     const int lane = threadIdx.x;
     const Entry en = decode_entry(e, EntryMap{P.same, P.njz, P.wide});
@@ -565,6 +573,16 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
                     }
                 }
                 const unsigned long long kept = __ballot(mb != 0);
+                if (TEMP && mb != 0)
+                {
+                    const int slot = running + __popcll(kept & ((1ull << lane) - 1ull));
+                    if (slot < P.tmp_cap)
+                    {
+                        tmp_cj[(size_t)e * P.tmp_cap + slot] = (cell0 + scj) * NSUBC + cjo;
+                        tmp_mb[(size_t)e * P.tmp_cap + slot] = (unsigned char)mb;
+                    }
+                    npairs += __popc(mb);
+                }
                 if (FILL && mb != 0)
                 {
                     const int slot = running + __popcll(kept & ((1ull << lane) - 1ull));
@@ -583,12 +601,61 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
             }
         }
     }
-    if (!FILL) { if (lane == 0) { ncj[e] = running; } }
-    else
+    if (!FILL)
+    {
+        if (lane == 0)
+        {
+            ncj[e] = running;
+            if (TEMP && running > P.tmp_cap) { atomicOr(overflow, 1); }
+        }
+    }
+    if (FILL || TEMP)
     {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) { npairs += __shfl_xor(npairs, m); }
         if (lane == 0 && npairs) { atomicAdd(nci_tot, npairs); }
+    }
+}
+
+// MODE 2's second half: one wave per entry, one lane per cj4 group: slots 4g .. 4g+3 of the entry's scratch range
+// become group cj4_start[e] + g, whole (padding slots zero, no exclusion words yet), and the groups that hold the
+// entry's own clusters are marked as needing exclusion words, exactly as MODE 1 leaves them.
+__global__ void __launch_bounds__(64)
+k_list_compact(EntryMap em, int cap, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const int *__restrict__ tmp_cj,
+               const unsigned char *__restrict__ tmp_mb, nbx_cj4_t *__restrict__ cj4, int *__restrict__ need_excl)
+{
+    const int e = blockIdx.x;
+    const int n = ncj[e];
+    if (n == 0) { return; }
+    const Entry en      = decode_entry(e, em);
+    const bool  central = em.same && shift_index(en.tx, en.ty, en.tz) == NBX_CENTRAL;
+    const int   base4   = cj4_start[e];
+    for (int gi = threadIdx.x; 4 * gi < n; gi += 64)
+    {
+        nbx_cj4_t grp;
+        unsigned  imask = 0;
+        bool      own   = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int slot = 4 * gi + k;
+            int       cj   = 0;
+            if (slot < n)
+            {
+                cj = tmp_cj[(size_t)e * cap + slot];
+                imask |= (unsigned)tmp_mb[(size_t)e * cap + slot] << (8 * k);
+                own = own || (central && (cj / NSUBC) == en.sci);
+            }
+            grp.cj[k] = cj;
+        }
+        grp.imei[0].imask = imask; grp.imei[0].excl_ind = 0;
+        grp.imei[1].imask = imask; grp.imei[1].excl_ind = 0;
+        cj4[base4 + gi] = grp;
+        if (own)
+        {
+            need_excl[2 * (base4 + gi)]     = 1;
+            need_excl[2 * (base4 + gi) + 1] = 1;
+        }
     }
 }
 
@@ -859,6 +926,9 @@ struct nbx_search {
     Buf<nbx_sci_t>  sci_a, sci_b;
     Buf<unsigned>   skey_in, skey_out;
     Buf<int>        sort_hist, sort_first;
+    int                 list_cap = LIST_TMP_CAP;
+    Buf<int>            tmp_cj;   // k_list MODE 2: list_cap j-clusters per entry ...
+    Buf<unsigned char>  tmp_mb;   // ... and their i-cluster masks
     nbx_prim_tmp    tmp;
     // pinned landing area for the handful of integers the host needs (array sizes): a device-to-host copy into
     // pageable memory is staged and costs ~25 us each, into pinned memory a third of that
@@ -868,6 +938,7 @@ struct nbx_search {
 nbx_search *nbx_search_create()
 {
     nbx_search *s = new nbx_search();
+    if (const char *env = getenv("GMX_HIP_NB_LIST_TMP_CAP")) { s->list_cap = std::max(4, atoi(env)); }
     if (hipHostMalloc((void **)&s->h_pin, 16 * sizeof(int), hipHostMallocPortable) != hipSuccess) { s->h_pin = nullptr; }
     return s;
 }
@@ -880,7 +951,7 @@ void nbx_search_destroy(nbx_search *s)
     s->bb.release(); s->bbcz.release(); s->bbsc.release(); s->zrange.release();
     s->ncj.release(); s->ncj4_e.release(); s->cj4_start.release(); s->need_excl.release(); s->excl_rank.release();
     s->nparts.release(); s->part_start.release(); s->cj4.release(); s->excl.release(); s->sci_a.release(); s->sci_b.release();
-    s->skey_in.release(); s->skey_out.release(); s->sort_hist.release(); s->sort_first.release();
+    s->skey_in.release(); s->skey_out.release(); s->sort_hist.release(); s->sort_first.release(); s->tmp_cj.release(); s->tmp_mb.release();
     nbx_prim_free(s->tmp);
     if (s->h_pin) { (void)hipHostFree(s->h_pin); }
     delete s;
@@ -923,8 +994,8 @@ int nbx_search_grid_columns(nbx_search *s, hipStream_t st, int zone, const float
         }
         s->byx = box[3]; s->bzx = box[6]; s->bzy = box[7];
         s->nzones = 0; s->nzones_filled = 0; s->natoms = 0; s->nc = 0; s->nsubc_tot0 = -1;
-        if (s->counters.reserve(16)) { return 1; }
-        S_TRY(hipMemsetAsync(s->counters.p, 0, 16 * sizeof(int), st));
+        if (s->counters.reserve(32)) { return 1; }
+        S_TRY(hipMemsetAsync(s->counters.p, 0, 32 * sizeof(int), st));
     }
     if (zone != s->nzones) { return sfail("zones must be gridded in order: got %d, expected %d", zone, s->nzones); }
     if (s->nzones_filled != 0) { return sfail("all zones get their columns before the first one is filled"); }
@@ -1108,9 +1179,25 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
 
     if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)
         || s->part_start.reserve(nent + 1)) { return 1; }
+    // one walk over the grid per entry, into a scratch range per entry (MODE 2 of k_list); the two-walk route only
+    // when an entry outgrows its range.  The scratch is not cleared: the compaction reads what ncj[e] says was written.
+    P.tmp_cap = s->list_cap;
+    const bool one_walk = (size_t)nent * P.tmp_cap * (sizeof(int) + 1) <= ((size_t)4 << 30);
+    if (one_walk && (s->tmp_cj.reserve((size_t)nent * P.tmp_cap) || s->tmp_mb.reserve((size_t)nent * P.tmp_cap))) { return 1; }
+    int *overflow = cnt + 20;
     S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));
-    hipLaunchKernelGGL((k_list<false>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
-                       (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)nullptr);
+    S_TRY(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    if (one_walk)
+    {
+        hipLaunchKernelGGL((k_list<2>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
+                           (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)(cnt + 1), s->tmp_cj.p, s->tmp_mb.p, overflow);
+    }
+    else
+    {
+        hipLaunchKernelGGL((k_list<0>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
+                           (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                           (unsigned char *)nullptr, (int *)nullptr);
+    }
     hipLaunchKernelGGL(k_groups_of, dim3(blocks_for(nent + 1, 256)), dim3(256), 0, st, nent, s->ncj.p, s->ncj4_e.p);
     S_TRY(hipGetLastError());
     S_TRY(nbx_prim_exclusive_sum(s->tmp, s->ncj4_e.p, s->cj4_start.p, nent + 1, st));
@@ -1118,6 +1205,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     if (!s->h_pin) { return sfail("no pinned host memory for the search"); }
     S_TRY(hipMemcpyAsync(&s->h_pin[1], s->cj4_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipMemcpyAsync(&s->h_pin[2], cnt + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&s->h_pin[7], overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
     h1[0] = s->h_pin[1]; h1[1] = s->h_pin[2];
     const int ncj4  = h1[0];
@@ -1125,10 +1213,19 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced, same ? 1.0 : 0.25);
 
     if (s->cj4.reserve((size_t)ncj4 + 1) || s->need_excl.reserve(2 * (size_t)ncj4 + 1) || s->excl_rank.reserve(2 * (size_t)ncj4 + 1)) { return 1; }
-    S_TRY(hipMemsetAsync(s->cj4.p, 0, ((size_t)ncj4 + 1) * sizeof(nbx_cj4_t), st));
     S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
-    hipLaunchKernelGGL((k_list<true>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
-                       s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1));
+    if (one_walk && s->h_pin[7] == 0)
+    {
+        hipLaunchKernelGGL(k_list_compact, dim3(nent), dim3(64), 0, st, em, P.tmp_cap, s->ncj.p, s->cj4_start.p, s->tmp_cj.p, s->tmp_mb.p, s->cj4.p,
+                           s->need_excl.p);
+    }
+    else
+    {
+        S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));   // the pair count of a walk that overflowed is not used
+        S_TRY(hipMemsetAsync(s->cj4.p, 0, ((size_t)ncj4 + 1) * sizeof(nbx_cj4_t), st));
+        hipLaunchKernelGGL((k_list<1>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
+                           s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1), (int *)nullptr, (unsigned char *)nullptr, (int *)nullptr);
+    }
     hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
     hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, em, s->ncj.p, s->cj4_start.p, s->cj4.p,

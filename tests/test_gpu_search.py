@@ -440,3 +440,24 @@ def test_progressive_balance_switch(nb):
     len0 = np.sort(lists[0].sci["cj4_ind_end"] - lists[0].sci["cj4_ind_start"])
     len1 = np.sort(lists[1].sci["cj4_ind_end"] - lists[1].sci["cj4_ind_start"])
     assert len1.max() > len0.max() and np.median(len1[:len(len1) // 8]) <= np.median(len0[:len(len0) // 8])   # ... cut differently
+
+
+def test_list_scratch_overflow_takes_the_two_walk_route():
+    """The list is normally made in one walk per entry into a scratch range of 512 j-clusters; an entry that outgrows
+    its range sends the whole list through the count + fill walks instead.  With the range cut to 8 every entry
+    overflows: the list must still be the host builder's."""
+    import os
+    s = g.system.water_box(2, 2, 2, model="spce")
+    ip = g.system.ewald(0.9, rlist=1.0)
+    p = g.workload.prepare(s, ip, 400)
+    os.environ["GMX_HIP_NB_LIST_TMP_CAP"] = "8"
+    try:
+        h = g.gpu.NbnxnHip(0)           # the search state (and its range size) is made per handle, on first use
+        _device_search(h, s, ip, 400)
+    finally:
+        del os.environ["GMX_HIP_NB_LIST_TMP_CAP"]
+    _assert_same_list(h.download_pairlist(), p.pl)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    f, elj, eel = _forces_resident(h, abi.FORCE_VIRIAL)
+    assert relrms(f, o["f"]) < FORCE_RTOL
+    h.close()
