@@ -617,45 +617,51 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
     }
 }
 
-// MODE 2's second half: one wave per entry, one lane per cj4 group: slots 4g .. 4g+3 of the entry's scratch range
-// become group cj4_start[e] + g, whole (padding slots zero, no exclusion words yet), and the groups that hold the
-// entry's own clusters are marked as needing exclusion words, exactly as MODE 1 leaves them.
-__global__ void __launch_bounds__(64)
-k_list_compact(EntryMap em, int cap, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const int *__restrict__ tmp_cj,
-               const unsigned char *__restrict__ tmp_mb, nbx_cj4_t *__restrict__ cj4, int *__restrict__ need_excl)
+// MODE 2's second half, one thread per cj4 group of the list: the group's entry is the last one that starts at or
+// before it (entries without groups share their start with the next one that has some); slots 4g .. 4g+3 of that
+// entry's scratch range become the group, whole (padding slots zero, no exclusion words yet), and the groups that
+// hold the entry's own clusters are marked as needing exclusion words, exactly as MODE 1 leaves them.
+__global__ void __launch_bounds__(256)
+k_list_compact(EntryMap em, int cap, int nent, int ncj4, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
+               const int *__restrict__ tmp_cj, const unsigned char *__restrict__ tmp_mb, nbx_cj4_t *__restrict__ cj4,
+               int *__restrict__ need_excl)
 {
-    const int e = blockIdx.x;
-    const int n = ncj[e];
-    if (n == 0) { return; }
+    const int g4 = blockIdx.x * 256 + threadIdx.x;
+    if (g4 >= ncj4) { return; }
+    int lo = 0, hi = nent - 1;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cj4_start[mid] <= g4) { lo = mid; } else { hi = mid - 1; }
+    }
+    const int   e       = lo;
+    const int   n       = ncj[e];
+    const int   gi      = g4 - cj4_start[e];
     const Entry en      = decode_entry(e, em);
     const bool  central = em.same && shift_index(en.tx, en.ty, en.tz) == NBX_CENTRAL;
-    const int   base4   = cj4_start[e];
-    for (int gi = threadIdx.x; 4 * gi < n; gi += 64)
-    {
-        nbx_cj4_t grp;
-        unsigned  imask = 0;
-        bool      own   = false;
+    nbx_cj4_t   grp;
+    unsigned    imask = 0;
+    bool        own   = false;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++)
+    {
+        const int slot = 4 * gi + k;
+        int       cj   = 0;
+        if (slot < n)
         {
-            const int slot = 4 * gi + k;
-            int       cj   = 0;
-            if (slot < n)
-            {
-                cj = tmp_cj[(size_t)e * cap + slot];
-                imask |= (unsigned)tmp_mb[(size_t)e * cap + slot] << (8 * k);
-                own = own || (central && (cj / NSUBC) == en.sci);
-            }
-            grp.cj[k] = cj;
+            cj = tmp_cj[(size_t)e * cap + slot];
+            imask |= (unsigned)tmp_mb[(size_t)e * cap + slot] << (8 * k);
+            own = own || (central && (cj / NSUBC) == en.sci);
         }
-        grp.imei[0].imask = imask; grp.imei[0].excl_ind = 0;
-        grp.imei[1].imask = imask; grp.imei[1].excl_ind = 0;
-        cj4[base4 + gi] = grp;
-        if (own)
-        {
-            need_excl[2 * (base4 + gi)]     = 1;
-            need_excl[2 * (base4 + gi) + 1] = 1;
-        }
+        grp.cj[k] = cj;
+    }
+    grp.imei[0].imask = imask; grp.imei[0].excl_ind = 0;
+    grp.imei[1].imask = imask; grp.imei[1].excl_ind = 0;
+    cj4[g4] = grp;
+    if (own)
+    {
+        need_excl[2 * g4]     = 1;
+        need_excl[2 * g4 + 1] = 1;
     }
 }
 
@@ -1216,8 +1222,11 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
     if (one_walk && s->h_pin[7] == 0)
     {
-        hipLaunchKernelGGL(k_list_compact, dim3(nent), dim3(64), 0, st, em, P.tmp_cap, s->ncj.p, s->cj4_start.p, s->tmp_cj.p, s->tmp_mb.p, s->cj4.p,
-                           s->need_excl.p);
+        if (ncj4 > 0)
+        {
+            hipLaunchKernelGGL(k_list_compact, dim3(blocks_for(ncj4, 256)), dim3(256), 0, st, em, P.tmp_cap, nent, ncj4, s->ncj.p, s->cj4_start.p,
+                               s->tmp_cj.p, s->tmp_mb.p, s->cj4.p, s->need_excl.p);
+        }
     }
     else
     {
