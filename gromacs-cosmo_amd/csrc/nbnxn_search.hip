@@ -256,7 +256,7 @@ k_supercells(int cell0, int nc, int ncxy, GridDims g, const int *__restrict__ cx
              const int *__restrict__ atom_start, const int *__restrict__ sorted_atom, const float *__restrict__ x,
              const float *__restrict__ q, const int *__restrict__ type, int dummy_type, int *__restrict__ a_out,
              int *__restrict__ cell_out, float4 *__restrict__ xq, int *__restrict__ type_out, float *__restrict__ bb,
-             float *__restrict__ bbcz, float *__restrict__ bbsc, int *__restrict__ nsubc, int *__restrict__ nsubc_tot)
+             float *__restrict__ bbcz, float *__restrict__ bbsc, int *__restrict__ nsubc)
 {
     const int sc   = blockIdx.x;          // zone-local; the per-cell arrays are indexed globally (cell0 + sc)
     const int scg  = cell0 + sc;
@@ -334,7 +334,8 @@ k_supercells(int cell0, int nc, int ncxy, GridDims g, const int *__restrict__ cx
         bbcz[2 * scg + 1] = z_last;
 #pragma unroll
         for (int d = 0; d < 3; d++) { bbsc[6 * scg + d] = blo[d]; bbsc[6 * scg + 3 + d] = bhi[d]; }
-        atomicAdd(nsubc_tot, ns);
+        // (the zone's cluster total is summed by k_zrange: one atomic per super-cell on a single counter cost
+        // 240 us of this kernel's 290 at 1.53 M atoms)
     }
 
     const size_t gi = (size_t)scg * NA_SC + lane;
@@ -356,8 +357,11 @@ k_supercells(int cell0, int nc, int ncxy, GridDims g, const int *__restrict__ cx
 }
 
 // z-range of all atoms as order-preserving keys: the cells of a column are ordered in z, so the first and
-// the last cell of every column suffice.  One block; zrange was initialised to {max key, 0}.
-__global__ void k_zrange(int cell0, int ncxy, const int *__restrict__ cxy_ind, const float *__restrict__ bbcz, unsigned *__restrict__ zrange)
+// the last cell of every column suffice.  Also the number of clusters with atoms in the zone (nbnxn_search.c's
+// grid->nsubc_tot, which sizes the list split).  One block; zrange was initialised to {max key, 0}.
+__global__ void __launch_bounds__(256)
+k_zrange(int cell0, int nc, int ncxy, const int *__restrict__ cxy_ind, const float *__restrict__ bbcz, const int *__restrict__ nsubc,
+         unsigned *__restrict__ zrange, int *__restrict__ nsubc_tot)
 {
     unsigned kmin = 0xffffffffu, kmax = 0u;
     for (int c = threadIdx.x; c < ncxy; c += blockDim.x)
@@ -371,6 +375,14 @@ __global__ void k_zrange(int cell0, int ncxy, const int *__restrict__ cxy_ind, c
     }
     atomicMin(&zrange[0], kmin);
     atomicMax(&zrange[1], kmax);
+    int sum = 0;
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) { sum += nsubc[cell0 + c]; }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { sum += __shfl_xor(sum, m); }
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) { *nsubc_tot = part[0] + part[1] + part[2] + part[3]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -613,7 +625,8 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
     {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) { npairs += __shfl_xor(npairs, m); }
-        if (lane == 0 && npairs) { atomicAdd(nci_tot, npairs); }
+        // 64 counters, not one: an atomic per entry on a single address serialises (hundreds of thousands of entries)
+        if (lane == 0 && npairs) { atomicAdd(nci_tot + (e & 63), npairs); }
     }
 }
 
@@ -923,6 +936,7 @@ struct nbx_search {
     Zone  zone[MAX_ZONES];
     // per super-cell / cluster / atom, all zones, global numbering
     Buf<int>      a, cell, nsubc, counters;
+    Buf<unsigned> nci_slots;   // 64 partial counts of the cluster pairs of the list being made
     Buf<float>    bb, bbcz, bbsc;
     Buf<unsigned> zrange;
     // list
@@ -945,7 +959,7 @@ nbx_search *nbx_search_create()
 {
     nbx_search *s = new nbx_search();
     if (const char *env = getenv("GMX_HIP_NB_LIST_TMP_CAP")) { s->list_cap = std::max(4, atoi(env)); }
-    if (hipHostMalloc((void **)&s->h_pin, 16 * sizeof(int), hipHostMallocPortable) != hipSuccess) { s->h_pin = nullptr; }
+    if (hipHostMalloc((void **)&s->h_pin, 96 * sizeof(int), hipHostMallocPortable) != hipSuccess) { s->h_pin = nullptr; }
     return s;
 }
 
@@ -953,7 +967,7 @@ void nbx_search_destroy(nbx_search *s)
 {
     if (!s) { return; }
     for (Zone &z : s->zone) { z.release(); }
-    s->a.release(); s->cell.release(); s->nsubc.release(); s->counters.release();
+    s->a.release(); s->cell.release(); s->nsubc.release(); s->counters.release(); s->nci_slots.release();
     s->bb.release(); s->bbcz.release(); s->bbsc.release(); s->zrange.release();
     s->ncj.release(); s->ncj4_e.release(); s->cj4_start.release(); s->need_excl.release(); s->excl_rank.release();
     s->nparts.release(); s->part_start.release(); s->cj4.release(); s->excl.release(); s->sci_a.release(); s->sci_b.release();
@@ -1077,8 +1091,9 @@ int nbx_search_grid_fill(nbx_search *s, hipStream_t st, int zone, const float *d
     Zone &z = s->zone[zone];
     hipLaunchKernelGGL(k_supercells, dim3(z.nc), dim3(64), 0, st, z.cell0, z.nc, z.ncxy, z.g, z.cxy_ind.p, z.cxy_na.p, z.atom_start.p,
                        z.sorted_atom.p, d_x, d_q, d_type, ntype_with_dummy - 1, s->a.p, s->cell.p, d_xq, d_type_out, s->bb.p,
-                       s->bbcz.p, s->bbsc.p, s->nsubc.p, s->counters.p + 2 + zone);
-    hipLaunchKernelGGL(k_zrange, dim3(1), dim3(256), 0, st, z.cell0, z.ncxy, z.cxy_ind.p, s->bbcz.p, s->zrange.p + 2 * zone);
+                       s->bbcz.p, s->bbsc.p, s->nsubc.p);
+    hipLaunchKernelGGL(k_zrange, dim3(1), dim3(256), 0, st, z.cell0, z.nc, z.ncxy, z.cxy_ind.p, s->bbcz.p, s->nsubc.p, s->zrange.p + 2 * zone,
+                       s->counters.p + 2 + zone);
     S_TRY(hipGetLastError());
     s->nzones_filled = zone + 1;
     return 0;
@@ -1181,7 +1196,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
         zp.rbb2 = r * r;
     }
     const int nent = zi.nc * entries_per_cell(em);
-    int      *cnt  = s->counters.p;   // [1] nci_tot of the list being made, [2 + z] clusters with atoms of zone z
+    int      *cnt  = s->counters.p;   // [2 + z] clusters with atoms of zone z, [20] scratch overflow flag
 
     if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)
         || s->part_start.reserve(nent + 1)) { return 1; }
@@ -1191,12 +1206,13 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     const bool one_walk = (size_t)nent * P.tmp_cap * (sizeof(int) + 1) <= ((size_t)4 << 30);
     if (one_walk && (s->tmp_cj.reserve((size_t)nent * P.tmp_cap) || s->tmp_mb.reserve((size_t)nent * P.tmp_cap))) { return 1; }
     int *overflow = cnt + 20;
-    S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));
+    if (s->nci_slots.reserve(64)) { return 1; }
+    S_TRY(hipMemsetAsync(s->nci_slots.p, 0, 64 * sizeof(unsigned), st));
     S_TRY(hipMemsetAsync(overflow, 0, sizeof(int), st));
     if (one_walk)
     {
         hipLaunchKernelGGL((k_list<2>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
-                           (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, (unsigned *)(cnt + 1), s->tmp_cj.p, s->tmp_mb.p, overflow);
+                           (const int *)nullptr, (nbx_cj4_t *)nullptr, (int *)nullptr, s->nci_slots.p, s->tmp_cj.p, s->tmp_mb.p, overflow);
     }
     else
     {
@@ -1230,10 +1246,10 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     }
     else
     {
-        S_TRY(hipMemsetAsync(cnt + 1, 0, sizeof(int), st));   // the pair count of a walk that overflowed is not used
+        S_TRY(hipMemsetAsync(s->nci_slots.p, 0, 64 * sizeof(unsigned), st));   // the pair count of a walk that overflowed is not used
         S_TRY(hipMemsetAsync(s->cj4.p, 0, ((size_t)ncj4 + 1) * sizeof(nbx_cj4_t), st));
         hipLaunchKernelGGL((k_list<1>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
-                           s->cj4_start.p, s->cj4.p, s->need_excl.p, (unsigned *)(cnt + 1), (int *)nullptr, (unsigned char *)nullptr, (int *)nullptr);
+                           s->cj4_start.p, s->cj4.p, s->need_excl.p, s->nci_slots.p, (int *)nullptr, (unsigned char *)nullptr, (int *)nullptr);
     }
     hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
@@ -1245,9 +1261,10 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     int h2[3] = {0, 0, 0};
     S_TRY(hipMemcpyAsync(&s->h_pin[3], s->excl_rank.p + 2 * ncj4, sizeof(int), hipMemcpyDeviceToHost, st));
     S_TRY(hipMemcpyAsync(&s->h_pin[4], s->part_start.p + nent, sizeof(int), hipMemcpyDeviceToHost, st));
-    S_TRY(hipMemcpyAsync(&s->h_pin[5], cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    S_TRY(hipMemcpyAsync(&s->h_pin[16], s->nci_slots.p, 64 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     S_TRY(hipStreamSynchronize(st));
-    h2[0] = s->h_pin[3]; h2[1] = s->h_pin[4]; h2[2] = s->h_pin[5];
+    h2[0] = s->h_pin[3]; h2[1] = s->h_pin[4]; h2[2] = 0;
+    for (int k = 0; k < 64; k++) { h2[2] += s->h_pin[16 + k]; }
     const int nexcl = 1 + h2[0], nsci = h2[1], nci_tot = h2[2];
 
     if (s->excl.reserve(nexcl) || s->sci_a.reserve((size_t)nsci + 1) || s->sci_b.reserve((size_t)nsci + 1) || s->skey_in.reserve((size_t)nsci + 1)
