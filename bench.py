@@ -227,6 +227,7 @@ def main():
         # device) sends them through torch.distributed instead
         rccl_direct = not rehearsal and os.environ.get("BENCH_DD_TORCH") != "1"
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct)
+        rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
         pair_slots = run.pair_slots_local    # summed over ranks below

@@ -18,6 +18,7 @@ Everything that moves between ranks is a torch tensor handed to torch.distribute
 (device buffers wrapped in place, local / non-local HIP streams); tests/test_dd_cpu.py binds
 them to the oracle instead.
 """
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -394,6 +395,19 @@ class SlabRun:
         nb.set_clear_in_kernel(True)
         self._views = {}
         self.f_t, self.out_t = self._current_views()
+        if rccl_direct:
+            # every rank checks on its own that the module can reach RCCL (library found, symbols bound, an id made),
+            # and the ranks agree before any of them enters the collective set-up: a rank without it would leave the
+            # others waiting.  Without it the messages go through torch.distributed.
+            ok = 1
+            try:
+                nb.dd_get_unique_id()
+            except gpu.HipError as err:
+                ok = 0
+                print(f"rank {rank}: the module's RCCL path is not available ({err}); using torch.distributed", file=sys.stderr, flush=True)
+            t = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            rccl_direct = bool(int(t.item()))
         self.device_halo, self.rccl_direct = device_halo, rccl_direct
         if rccl_direct:
             self.halo = RcclHalo(nb, dom, self.dev)
