@@ -240,8 +240,10 @@ def main():
         if args.mcb >= 0 or args.variant >= 0 or args.no_split:
             raise SystemExit("--mcb/--variant/--no-split are single-GPU A/B switches")
 
+    finish = run.flush if decomposed else (lambda: None)   # what the last step left for the next one to issue
     for _ in range(args.warmup):
         step()
+    finish()
     sync()
     if decomposed:
         dist.barrier()
@@ -250,6 +252,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k] if k % args.event_every == 0 else None)
+    finish()
     sync()
     if decomposed:
         dist.barrier()

@@ -409,6 +409,7 @@ class SlabRun:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             rccl_direct = bool(int(t.item()))
         self.device_halo, self.rccl_direct = device_halo, rccl_direct
+        self._reduction_owed = False
         if rccl_direct:
             self.halo = RcclHalo(nb, dom, self.dev)
         else:
@@ -439,9 +440,9 @@ class SlabRun:
 
     def step(self, ev=None):
         nb, fl = self.nb, self.flags
-        nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
         if self.rccl_direct:
             return self._step_rccl_direct(ev)
+        nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
         if not self.device_halo:
             return self._step_torch_halo(ev)
         if ev:
@@ -461,21 +462,34 @@ class SlabRun:
         torch.cuda.set_stream(self.s_default)
 
     def _step_rccl_direct(self, ev=None):
-        """the same step with the module issuing its own RCCL calls: seven calls through the C ABI"""
+        """The same step with the module issuing its own RCCL calls, in an order chosen for what RCCL's kernels need.
+
+        RCCL runs one communicator's operations in the order they were issued, and its send / receive kernel cannot
+        start once the local kernel holds every wave slot.  So the coordinate exchange of THIS step
+        is issued before the slot reduction of the LAST one: it runs on an idle chip right after the last step's forces
+        came back, the reduction follows it on the local stream, and the local kernel follows the reduction.  Issued the
+        other way round the exchange would become runnable at the same moment as the local kernel and could lose the
+        chip to it for the whole kernel.  The reduction is off the path to the next coordinates, as in an MD step, and
+        flush() issues the one still owed before anybody reads the energies."""
         nb, fl = self.nb, self.flags
+        nb.dd_move_x()                                    # non-local stream, behind the last step's returned forces
+        self.flush()                                      # local stream: the last step's slot reduction, if owed
+        nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
         if ev:
             ev[0].record(self.s_loc)
-        nb.launch_kernel_resident(fl, abi.LOCAL)
+        nb.launch_kernel_resident(fl, abi.LOCAL)          # also zeroes the idle output buffer (the one just reduced)
         if ev:
             ev[1].record(self.s_loc)
-        nb.dd_move_x()                                    # non-local stream: overlaps the local kernel
-        nb.launch_kernel_resident(fl, abi.NONLOCAL)
+        nb.launch_kernel_resident(fl, abi.NONLOCAL)       # beside the local kernel, once the halo has arrived
         nb.dd_move_f()
         nb.stream_wait(abi.LOCAL, abi.NONLOCAL)           # ONE cross-stream wait: what follows on the local stream sees all of it
-        if fl & abi.FORCE_VIRIAL:
-            # on the local stream, so that the next step's coordinate exchange (non-local stream) need not wait for it;
-            # every rank issues its RCCL calls in the same order, and RCCL runs one communicator's kernels in launch order
-            nb.dd_sum_outputs(abi.LOCAL)
+        self._reduction_owed = bool(fl & abi.FORCE_VIRIAL)
+
+    def flush(self):
+        """issues what a step left for the next one to issue (the slot reduction of the module-issued RCCL route)"""
+        if self._reduction_owed:
+            self.nb.dd_sum_outputs(abi.LOCAL)
+            self._reduction_owed = False
 
     def _step_torch_halo(self, ev=None):
         """the same step with the halo buffers packed by torch indexing operations (HaloExchange)"""
@@ -500,6 +514,7 @@ class SlabRun:
 
     def read_energies(self):
         """{e_lj, e_el, fshift[45][3]} of the last step, summed over ranks (valid until the next step)."""
+        self.flush()
         torch.cuda.synchronize(self.dev)
         return fold_slots(self._current_views()[1])
 
