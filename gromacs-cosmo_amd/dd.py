@@ -442,24 +442,27 @@ class SlabRun:
         nb, fl = self.nb, self.flags
         if self.rccl_direct:
             return self._step_rccl_direct(ev)
-        nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
         if not self.device_halo:
+            nb.clear_outputs(fl)                          # a switch of output buffers (or a fill the first time)
             return self._step_torch_halo(ev)
+        # the same order of collectives as _step_rccl_direct, for the same reason (torch's RCCL stream also runs them in
+        # issue order): this step's coordinate exchange, then the last step's slot reduction, then the kernels.
+        # The collectives follow torch's CURRENT stream; set_stream costs a third of the context manager.
+        torch.cuda.set_stream(self.s_nl)
+        self.halo.send_x()                                # pack, exchange, unpack
+        self.flush()                                      # local stream: the last step's slot reduction, if owed
+        nb.clear_outputs(fl)
         if ev:
             ev[0].record(self.s_loc)
         nb.launch_kernel_resident(fl, abi.LOCAL)          # local stream; also zeroes the idle output buffer
         if ev:
             ev[1].record(self.s_loc)
-        # the collectives follow torch's CURRENT stream; set_stream costs a third of the context manager
-        torch.cuda.set_stream(self.s_nl)
-        self.halo.send_x()                                # pack, exchange, unpack: overlaps the local kernel
         nb.launch_kernel_resident(fl, abi.NONLOCAL)
+        torch.cuda.set_stream(self.s_nl)
         self.halo.return_f()                              # atomic adds: no need to wait for the local kernel
-        nb.stream_wait(abi.LOCAL, abi.NONLOCAL)           # ONE cross-stream wait per step: the reduction and the
-        torch.cuda.set_stream(self.s_loc)                 # next step's clear come after everything above
-        if fl & abi.FORCE_VIRIAL:
-            reduce_slots(self._current_views()[1])
+        nb.stream_wait(abi.LOCAL, abi.NONLOCAL)           # ONE cross-stream wait per step
         torch.cuda.set_stream(self.s_default)
+        self._reduction_owed = bool(fl & abi.FORCE_VIRIAL)
 
     def _step_rccl_direct(self, ev=None):
         """The same step with the module issuing its own RCCL calls, in an order chosen for what RCCL's kernels need.
@@ -486,9 +489,14 @@ class SlabRun:
         self._reduction_owed = bool(fl & abi.FORCE_VIRIAL)
 
     def flush(self):
-        """issues what a step left for the next one to issue (the slot reduction of the module-issued RCCL route)"""
+        """issues what a step left for the next one to issue: the slot reduction of the last step"""
         if self._reduction_owed:
-            self.nb.dd_sum_outputs(abi.LOCAL)
+            if self.rccl_direct:
+                self.nb.dd_sum_outputs(abi.LOCAL)
+            else:
+                torch.cuda.set_stream(self.s_loc)
+                reduce_slots(self._current_views()[1])
+                torch.cuda.set_stream(self.s_default)
             self._reduction_owed = False
 
     def _step_torch_halo(self, ev=None):
