@@ -78,6 +78,34 @@ def large_system_leg(g, abi, ip, flags, model, flops_pair, peak_tflops, tiles=(1
             "note": "wall time per step (not kernel events), same flavour and flop count as the headline workload"}
 
 
+def decomposed_step_leg(timeout_s=150):
+    """Secondary figure, outside the timed region of `value`: the domain-decomposed step (what --gpus N runs on every
+    rank) on ONE rank that is its own neighbour, so that the halo messages are real RCCL sends / receives on this one
+    GPU.  Run as a child process with a time limit (it brings up a process group and an RCCL communicator, which the
+    headline measurement must not depend on); any failure is reported instead of a number."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dd-self", "--no-cpu", "--steps", "200", "--warmup", "20"],
+                           env=env, capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-300:]}
+        d = json.loads(line[-1])
+        return {"ms_per_step": d["ms_per_step"], "pairs_per_s": d["value"], "parallelism": d["config"]["parallelism"],
+                "halo_atoms": d["config"].get("halo_atoms_rank0"), "local_kernel_ms": d["roofline"]["kernel_ms"],
+                "note": "python bench.py --dd-self: local + non-local kernels, halo x / f over RCCL (to itself), slot all-reduce, per step"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout_s} s"}
+    except (OSError, ValueError, KeyError) as err:
+        return {"error": repr(err)}
+
+
 def verlet_loop_leg(g, abi, system, ip, flags, nstlist=10, nsteps=100):
     """Secondary figure, outside the timed region of `value`: the whole device-resident step of
     gromacs-cosmo_amd/verlet.py (search on the device every nstlist steps, x gather, kernel, f scatter
@@ -320,6 +348,7 @@ def main():
             out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
             out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)
+            out["decomposed_step_one_rank"] = decomposed_step_leg()
         print(json.dumps(out), flush=True)
     if decomposed:
         sync()
