@@ -399,6 +399,15 @@ def test_device_search_with_a_halo_zone(nb, kind, rank):
     assert relrms(f, fo) < FORCE_RTOL
     assert abs(e_lj[0] - (o_l["Vvdw"] + o_n["Vvdw"])) < ENERGY_RTOL * abs(o_l["Vvdw"] + o_n["Vvdw"])
     assert abs(e_el[0] - (o_l["Vc"] + o_n["Vc"])) < ENERGY_RTOL * abs(o_l["Vc"] + o_n["Vc"])
+    if ip.rlist > ip.rcoulomb:
+        # dynamic pruning of the NON-LOCAL list too: a fresh list pruned to an inner radius by the prune-only kernel,
+        # its masks against the reference's pruning rule on the host list
+        nb.make_pairlist(ip.rlist, None, None, mcb, iloc=abi.NONLOCAL)
+        inner = 0.5 * (ip.rlist + ip.rcoulomb)
+        nb.prune_only(inner, 1, iloc=abi.NONLOCAL)
+        want = O.prune_list(xq, h.shift_vec(), pl_n, inner)["imei"]["imask"]
+        got = nb.download_pairlist(abi.NONLOCAL).cj4["imei"]["imask"]
+        assert np.array_equal(got, want) and (want != pl_n.cj4["imei"]["imask"]).any()
 
 
 def test_device_search_at_config4_size(nb):
