@@ -12,11 +12,15 @@ halo f).  The path's multi-GPU form here is the smallest scheme with the same da
   * per step: halo coordinates travel DOWN (r -> r-1), halo forces travel UP (r -> r+1) and are
     added to the owner's forces; {e_lj, e_el, fshift} are summed over ranks.
 
-Everything that moves between ranks is a torch tensor handed to torch.distributed
-(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests): `Domain` and
-`HaloExchange` work on CPU and GPU tensors alike.  `SlabRun` binds them to the HIP module
-(device buffers wrapped in place, local / non-local HIP streams); tests/test_dd_cpu.py binds
-them to the oracle instead.
+Three ways to move the halo, one data flow:
+  * `RcclHalo` (what bench.py --gpus N uses): the HIP module issues pack kernel, grouped RCCL send / receive and
+    unpack kernel itself on its non-local stream (nbnxn_hip_dd_*, its own communicator);
+  * `DeviceHalo`: the module's pack / unpack kernels, the messages through torch.distributed (backend "nccl" = RCCL
+    over xGMI on the GPU box, "gloo" in rehearsals on one GPU);
+  * `HaloExchange`: torch indexing operations and torch.distributed, on CPU and GPU tensors alike -- what
+    tests/test_dd_cpu.py binds to the oracle.
+`SlabRun` binds them to the HIP module (device buffers wrapped in place, local / non-local HIP streams).  One rank is
+a valid decomposition too: it is its own neighbour, periodic in z through a halo of its own atoms.
 """
 import sys
 from dataclasses import dataclass
@@ -79,7 +83,7 @@ class Domain:
 
 def _staged(t):
     """gloo moves host memory only: device tensors are staged through the host for it (the
-    one-GPU rehearsal of tests/test_gpu_dd.py); RCCL takes them as they are."""
+    one-GPU rehearsal of tests/test_gpu_z_dd.py); RCCL takes them as they are."""
     return t is not None and t.is_cuda and dist.get_backend() == "gloo"
 
 
