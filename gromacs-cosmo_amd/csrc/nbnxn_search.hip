@@ -691,13 +691,12 @@ __device__ __forceinline__ int cj_at(const nbx_cj4_t *cj4, int ind) { return cj4
 // (cj4 group, half) pairs that need an exclusion word set; APPLY = true clears the bits (also
 // the j > i masks of the entry's own clusters, set_self_and_newton_excls_supersub).
 template <bool APPLY>
-__global__ void __launch_bounds__(64)
-k_excl(int natoms, EntryMap em, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
-       const int *__restrict__ a, const int *__restrict__ cell, const int *__restrict__ excl_index,
-       const int *__restrict__ excl_a, int *__restrict__ need_excl, nbx_excl_t *__restrict__ excl)
+__device__ __forceinline__ void
+excl_entry(int e, int lane, int natoms, EntryMap em, const int *__restrict__ ncj, const int *__restrict__ cj4_start,
+           const nbx_cj4_t *__restrict__ cj4, const int *__restrict__ a, const int *__restrict__ cell,
+           const int *__restrict__ excl_index, const int *__restrict__ excl_a, int *__restrict__ need_excl,
+           nbx_excl_t *__restrict__ excl)
 {
-    const int e    = blockIdx.x;
-    const int lane = threadIdx.x;
     const int n    = ncj[e];
     if (n == 0) { return; }
     const Entry en     = decode_entry(e, em);
@@ -759,6 +758,24 @@ k_excl(int natoms, EntryMap em, const int *__restrict__ ncj, const int *__restri
                 atomicAnd(&excl[idx].pair[(inner_e & 3) * NA_C + inner_i], ~bit);
             }
         }
+    }
+}
+
+// A wave takes EXCL_EPW consecutive entries: most (cell, shift) combinations of a large box hold nothing, and a wave
+// per entry would be launched just to find that out (340 k waves at 1.53 M atoms, ~30 k of them with work).
+constexpr int EXCL_EPW = 8;
+
+template <bool APPLY>
+__global__ void __launch_bounds__(64)
+k_excl(int nent, int natoms, EntryMap em, const int *__restrict__ ncj, const int *__restrict__ cj4_start, const nbx_cj4_t *__restrict__ cj4,
+       const int *__restrict__ a, const int *__restrict__ cell, const int *__restrict__ excl_index,
+       const int *__restrict__ excl_a, int *__restrict__ need_excl, nbx_excl_t *__restrict__ excl)
+{
+    const int e0 = blockIdx.x * EXCL_EPW;
+    const int e1 = min(nent, e0 + EXCL_EPW);
+    for (int e = e0; e < e1; e++)
+    {
+        excl_entry<APPLY>(e, threadIdx.x, natoms, em, ncj, cj4_start, cj4, a, cell, excl_index, excl_a, need_excl, excl);
     }
 }
 
@@ -1251,7 +1268,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
         hipLaunchKernelGGL((k_list<1>), dim3(nent), dim3(64), 0, st, P, s->nsubc.p, s->bb.p, s->bbcz.p, s->bbsc.p, s->zrange.p, d_xq, s->ncj.p,
                            s->cj4_start.p, s->cj4.p, s->need_excl.p, s->nci_slots.p, (int *)nullptr, (unsigned char *)nullptr, (int *)nullptr);
     }
-    hipLaunchKernelGGL((k_excl<false>), dim3(nent), dim3(64), 0, st, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+    hipLaunchKernelGGL((k_excl<false>), dim3(blocks_for(nent, EXCL_EPW)), dim3(64), 0, st, nent, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, s->need_excl.p, (nbx_excl_t *)nullptr);
     hipLaunchKernelGGL((k_split<false>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, em, s->ncj.p, s->cj4_start.p, s->cj4.p,
                        nsp_max, s->progressive ? 1 : 0, s->nparts.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
@@ -1271,7 +1288,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
         || s->skey_out.reserve((size_t)nsci + 1)) { return 1; }
     hipLaunchKernelGGL(k_excl_init, dim3(blocks_for(2 * (size_t)ncj4 + 1, 256)), dim3(256), 0, st, 2 * ncj4, s->need_excl.p, s->excl_rank.p,
                        s->cj4.p, s->excl.p);
-    hipLaunchKernelGGL((k_excl<true>), dim3(nent), dim3(64), 0, st, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
+    hipLaunchKernelGGL((k_excl<true>), dim3(blocks_for(nent, EXCL_EPW)), dim3(64), 0, st, nent, s->natoms, em, s->ncj.p, s->cj4_start.p, s->cj4.p, s->a.p, s->cell.p,
                        d_excl_index, d_excl_a, (int *)nullptr, s->excl.p);
     hipLaunchKernelGGL((k_split<true>), dim3(blocks_for(nent + 1, 128)), dim3(128), 0, st, nent, em, s->ncj.p, s->cj4_start.p, s->cj4.p,
                        nsp_max, s->progressive ? 1 : 0, (int *)nullptr, s->part_start.p, s->sci_a.p);
