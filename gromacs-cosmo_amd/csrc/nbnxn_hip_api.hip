@@ -661,7 +661,28 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     nbnxn_hip *nb = new nbnxn_hip();
     nb->device      = device_id;
     nb->two_streams = bLocalAndNonlocal != 0;
-    HIP_TRY(hipStreamCreateWithFlags(&nb->stream[0], hipStreamNonBlocking));
+    // With two streams the local kernel fills every wave slot of the chip for the whole step (one-wave workgroups
+    // at 4 waves per SIMD, all 512 VGPRs of a SIMD taken), and RCCL's send / receive kernel -- two or three
+    // workgroups of 256 threads, 132 VGPRs, 20 KB LDS -- then finds no room until the local kernel drains (a 6 us
+    // kernel took 58 us, profiles/README r1_j).  So the local stream leaves one CU of every shader engine alone:
+    // CU-mask bit b is XCC b mod 8, engine (b / 8) mod 4, CU b / 32 of that engine (tools/ubench/cu_mask_probe.hip),
+    // i.e. the first 32 bits.  Workgroups are dealt to the engines in turn, so fewer than one CU per engine does not
+    // help (8 and 16 were tried).  The local kernel loses 12 % of its CUs and the exchange runs beside it: the
+    // decomposed step went from 0.105 to 0.098 ms on one rank.  GMX_HIP_NB_RESERVE_CUS overrides the count (0: off).
+    int reserve = nb->two_streams ? 32 : 0;
+    if (const char *env = getenv("GMX_HIP_NB_RESERVE_CUS")) { reserve = nb->two_streams ? atoi(env) : 0; }
+    reserve = std::max(0, std::min(reserve, prop.multiProcessorCount / 2));
+    if (reserve > 0)
+    {
+        std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+        for (int b = 0; b < reserve; b++) { mask[b / 32] &= ~(1u << (b % 32)); }
+        if (prop.multiProcessorCount % 32) { mask.back() &= (1u << (prop.multiProcessorCount % 32)) - 1; }
+        HIP_TRY(hipExtStreamCreateWithCUMask(&nb->stream[0], (uint32_t)mask.size(), mask.data()));
+    }
+    else
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&nb->stream[0], hipStreamNonBlocking));
+    }
     if (nb->two_streams)
     {
         // the non-local work sits on the critical path of the halo exchange: high priority
