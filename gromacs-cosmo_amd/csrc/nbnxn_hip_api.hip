@@ -95,6 +95,7 @@ struct PList {
 struct nbnxn_hip {
     int         device = 0;
     bool        two_streams = false;
+    int         reserved_cus = 0;   // CUs the local stream leaves to the non-local stream's work (CU mask)
     hipStream_t stream[2] = {nullptr, nullptr};
     hipEvent_t  misc_ops_done = nullptr, nonlocal_done = nullptr;
     hipEvent_t  stream_mark[2] = {nullptr, nullptr};   // nbnxn_hip_stream_wait
@@ -672,6 +673,7 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     int reserve = nb->two_streams ? 32 : 0;
     if (const char *env = getenv("GMX_HIP_NB_RESERVE_CUS")) { reserve = nb->two_streams ? atoi(env) : 0; }
     reserve = std::max(0, std::min(reserve, prop.multiProcessorCount / 2));
+    nb->reserved_cus = reserve;
     if (reserve > 0)
     {
         std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
@@ -1490,6 +1492,8 @@ int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const
     HIP_TRY(nbx_launch_halo_unpack_f(d_slots, n, d_buf, nb->f.p, entry, nb->stream[nb->two_streams ? iloc : 0]));
     return 0;
 }
+
+int nbnxn_hip_reserved_cus(nbnxn_hip_ptr_t nb) { return nb ? nb->reserved_cus : 0; }
 
 int nbnxn_hip_stream_wait(nbnxn_hip_ptr_t nb, int iloc_waits, int iloc_done)
 {

@@ -22,6 +22,7 @@ Three ways to move the halo, one data flow:
 `SlabRun` binds them to the HIP module (device buffers wrapped in place, local / non-local HIP streams).  One rank is
 a valid decomposition too: it is its own neighbour, periodic in z through a halo of its own atoms.
 """
+import os
 import sys
 from dataclasses import dataclass
 
@@ -414,6 +415,7 @@ class SlabRun:
             rccl_direct = bool(int(t.item()))
         self.device_halo, self.rccl_direct = device_halo, rccl_direct
         self._reduction_owed = False
+        self.exchange_beside_local = nb.reserved_cus() > 0 and os.environ.get("NBNXN_DD_X_FIRST") != "1"
         if rccl_direct:
             self.halo = RcclHalo(nb, dom, self.dev)
         else:
@@ -479,7 +481,9 @@ class SlabRun:
         chip to it for the whole kernel.  The reduction is off the path to the next coordinates, as in an MD step, and
         flush() issues the one still owed before anybody reads the energies."""
         nb, fl = self.nb, self.flags
-        nb.dd_move_x()                                    # non-local stream, behind the last step's returned forces
+        beside = self.exchange_beside_local               # the local stream leaves CUs free: RCCL's kernel finds room
+        if not beside:
+            nb.dd_move_x()                                # non-local stream, behind the last step's returned forces
         self.flush()                                      # local stream: the last step's slot reduction, if owed
         nb.clear_outputs(fl)                              # a switch of output buffers (or a fill the first time)
         if ev:
@@ -487,6 +491,8 @@ class SlabRun:
         nb.launch_kernel_resident(fl, abi.LOCAL)          # also zeroes the idle output buffer (the one just reduced)
         if ev:
             ev[1].record(self.s_loc)
+        if beside:
+            nb.dd_move_x()                                # non-local stream, beside the local kernel
         nb.launch_kernel_resident(fl, abi.NONLOCAL)       # beside the local kernel, once the halo has arrived
         nb.dd_move_f()
         nb.stream_wait(abi.LOCAL, abi.NONLOCAL)           # ONE cross-stream wait: what follows on the local stream sees all of it

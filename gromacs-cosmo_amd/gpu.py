@@ -116,6 +116,7 @@ def load():
     lib.nbnxn_hip_halo_pack_f.argtypes = [vp, vp, ci, vp, ci]
     lib.nbnxn_hip_halo_unpack_f.argtypes = [vp, vp, ci, vp, ci, ci]
     lib.nbnxn_hip_stream_wait.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_reserved_cus.argtypes = [vp]
     lib.nbnxn_hip_dd_get_unique_id.argtypes = [C.c_char_p]
     lib.nbnxn_hip_dd_init.argtypes = [vp, C.c_char_p, ci, ci]
     lib.nbnxn_hip_dd_set_pulse.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci]
@@ -396,6 +397,9 @@ class NbnxnHip:
 
     def halo_unpack_f(self, d_slots, n, d_buf, shift_index=-1, iloc=abi.NONLOCAL):
         self._chk(self.lib.nbnxn_hip_halo_unpack_f(self.h, d_slots, n, d_buf, shift_index, iloc))
+
+    def reserved_cus(self):
+        return int(self.lib.nbnxn_hip_reserved_cus(self.h))
 
     def stream_wait(self, iloc_waits, iloc_done):
         self._chk(self.lib.nbnxn_hip_stream_wait(self.h, iloc_waits, iloc_done))

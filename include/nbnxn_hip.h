@@ -583,6 +583,10 @@ int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const
 /* everything put on the stream of iloc_waits from here on runs after what the stream of
  * iloc_done holds now (two pre-made events, no allocation); a no-op on one-stream handles */
 int nbnxn_hip_stream_wait(nbnxn_hip_ptr_t nb, int iloc_waits, int iloc_done);
+/* Two-stream handles: how many CUs the local stream leaves free (a CU mask: one CU per shader engine by default,
+ * GMX_HIP_NB_RESERVE_CUS overrides, 0 = none), so that the halo exchange's kernels -- RCCL's above all -- can run
+ * beside a local kernel that would otherwise hold every wave slot.  No counterpart in the reference. */
+int nbnxn_hip_reserved_cus(nbnxn_hip_ptr_t nb);
 
 /* ------------------------------------------------------------------------------------
  * Domain decomposition over RCCL: the halo exchange of one decomposed dimension,
