@@ -679,9 +679,15 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
         std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
         for (int b = 0; b < reserve; b++) { mask[b / 32] &= ~(1u << (b % 32)); }
         if (prop.multiProcessorCount % 32) { mask.back() &= (1u << (prop.multiProcessorCount % 32)) - 1; }
-        HIP_TRY(hipExtStreamCreateWithCUMask(&nb->stream[0], (uint32_t)mask.size(), mask.data()));
+        // a platform that does not take CU masks gets an ordinary stream: the run is correct without the reservation
+        if (hipExtStreamCreateWithCUMask(&nb->stream[0], (uint32_t)mask.size(), mask.data()) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            nb->stream[0]    = nullptr;
+            nb->reserved_cus = 0;
+        }
     }
-    else
+    if (nb->stream[0] == nullptr)
     {
         HIP_TRY(hipStreamCreateWithFlags(&nb->stream[0], hipStreamNonBlocking));
     }
