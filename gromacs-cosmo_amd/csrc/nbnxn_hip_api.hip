@@ -483,6 +483,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
         a.k.rc2      = (float)(b * b * (double)nb->rcoulomb * (double)nb->rcoulomb);
         a.k.rlist2   = (float)(b * b * (double)pl.rlist * (double)pl.rlist);
         a.k.rvdw2    = (float)(b * b * (double)nb->rvdw * (double)nb->rvdw);
+        a.k.r2inc    = (float)(b * b * (double)NBX_AVOID_SING_R2_INC);
         // switch constants in scaled units: rsw' = beta rsw; a force-switch term c6' (c2 + c3 rsw') rsw'^2 / r'
         // with c6' = c6 beta^7 must equal (true term) / beta, which gives c2 / beta^9, c3 / beta^10 for
         // dispersion and c2 / beta^15, c3 / beta^16 for repulsion; potential switch c_n / beta^n

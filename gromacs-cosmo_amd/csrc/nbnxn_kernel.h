@@ -28,6 +28,7 @@ struct nbx_kernel_k_t {
     float escale;      // 1/beta | 1: multiplies the accumulated energies at the end
     float rc2, rlist2; // scaled cut-off and list radius, squared
     float rvdw2;       // scaled LJ cut-off squared (twin-range flavour)
+    float r2inc;       // NBX_AVOID_SING_R2_INC in scaled units (beta^2 x 1e-12 | 1e-12): added to r^2 of excluded pairs
     // LJ force / potential switch (forcerec.c:1942-1975), in the kernel's scaled units: with
     // r' = beta r the constants of a term c*rsw^n become c / beta^(n + its prefactor power),
     // see fill_kernel_consts in nbnxn_hip_api.hip

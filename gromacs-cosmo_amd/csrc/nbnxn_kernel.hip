@@ -204,9 +204,9 @@ __device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int 
 //    copies of them (24 more live registers, three moves per skipped pair, 24 per skipped
 //    j-cluster).  The single body pays two instructions per pair for exclusions instead: the
 //    pair's exclusion bit is sign-extended to a 0 / ~0 word and ANDed onto the terms that
-//    vanish for excluded pairs.  r = 0 only occurs for the self pair, whose result the
-//    cut-off select discards, so no r^2 increment is needed (fillers sit at distinct
-//    positions, nbnxn_atomdata.c:288-295).
+//    vanish for excluded pairs.  Excluded pairs get the reference's r^2 increment (see
+//    pair_interaction): r = 0 occurs for the self pair, whose result the cut-off select
+//    discards, and for distinct excluded atoms on one point, whose corrections must stay finite.
 //  * the software pipeline works per j-cluster (two rolling j-atom register sets instead of
 //    two four-cluster batches);
 //  * the eight LJ parameter pairs of a j-cluster are fetched from LDS before its first pair
@@ -220,15 +220,25 @@ __device__ __forceinline__ float and_mask(const float v, const int m)
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
 __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
                                         const float2 c, const float c6g, const unsigned wexcl, const int bitpos, const bool allowed,
+                                        const float r2inc,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
                                         float &E_lj, float &E_el, bool &any_in_rlist)
 {
     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    // 0 for an excluded pair, all ones otherwise
+    int         m;
+    float       r2e;
+    // (both as asm: left to itself the compiler turns the pair into v_and + v_cmp + two v_cndmask + a v_mov)
+    __asm__("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(wexcl), "n"(bitpos));
+    __asm__("v_bfi_b32 %0, %1, 0, %2" : "=v"(r2e) : "v"(m), "s"(r2inc));     // ~m & r2inc
+    // the reference's r^2 += (1 - int_bit) * NBNXN_AVOID_SING_R2_INC (nbnxn_consts.h:66-79,
+    // nbnxn_cuda_kernel.cuh:371, nbnxn_kernel_ref_inner.h:132): two distinct, mutually excluded atoms may sit on
+    // one point (shells, virtual sites); their Ewald / reaction-field / LJ-PME correction must stay finite.  The
+    // increment (in the kernel's scaled units) rides in the first fma of the distance, so it costs the one mask
+    // instruction; it is far below an ulp of rc^2 / rlist^2, so cut-off and pruning decisions are the reference's.
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, r2e)));
     if (PRUNE) { any_in_rlist = __any(r2 < a.k.rlist2); }
     const bool  cond = (r2 < a.k.rc2) && allowed;
-    // 0 for an excluded pair, all ones otherwise
-    const int   m      = __builtin_amdgcn_sbfe((int)wexcl, bitpos, 1);
     const float inv_r  = __builtin_amdgcn_rsqf(r2);
     const float inv_r2 = inv_r * inv_r;
     const float inv_r6 = inv_r2 * inv_r2 * inv_r2;
@@ -438,7 +448,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi,
+            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, a.k.r2inc,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }

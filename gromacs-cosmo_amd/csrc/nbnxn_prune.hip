@@ -39,7 +39,9 @@ nbnxn_prune_kernel(const float4 *__restrict__ xq, const float *__restrict__ shif
     // software pipeline as in the force kernel: the next group's mask and j-cluster indices are requested
     // before this group's arithmetic, and a group's four j-atoms (one per lane and cluster) all at once
     auto load_hdr = [&](int j4, unsigned &in, int (&cj)[4]) {
-        in = FRESH ? cj4[j4].imei[0].imask : imask_outer[j4];
+        // a list pruned per 32-lane half by the reference's own kernels carries two different masks
+        // (nbnxn_cuda_kernel.cuh:503): their union is what a wave64 walks, here as in the force kernel
+        in = FRESH ? (cj4[j4].imei[0].imask | cj4[j4].imei[1].imask) : imask_outer[j4];
 #pragma unroll
         for (int jm = 0; jm < 4; jm++) { cj[jm] = ((in >> (8 * jm)) & 0xffu) ? cj4[j4].cj[jm] : 0; }   // unused slots hold anything
     };

@@ -219,6 +219,17 @@ def ref_kernel_gpu_ref(xq, type_, ntype, nbfp, shift_vec, pl, ip, calc_ener=True
     return dict(f=f, fshift=fshift, Vc=vc.value, Vvdw=vv.value)
 
 
+def ref_ewald_table(ip):
+    """(FDV0 [n, 4] float32, scale) of the Coulomb table the compiled reference kernels consume for `ip`
+    (oracle/ref_harness.c make_ic: the harness's restatement of tables.c:165-369 / forcerec.c:1865-1905)."""
+    p = ref_params(ip)
+    sc = C.c_float(0)
+    n = reflib().ref_ewald_table(C.byref(p), C.byref(sc), None, 0)
+    out = np.zeros((n, 4), dtype=np.float32)
+    reflib().ref_ewald_table(C.byref(p), C.byref(sc), _p(out), out.size)
+    return out, sc.value
+
+
 class RefKernelRef:
     """The reference's nbnxn_kernel_ref (plain-C 4x4) on the simple list derived from the GPU list."""
 

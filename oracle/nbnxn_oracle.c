@@ -174,8 +174,21 @@ static double pair_term(const oracle_params_t *p, double rsq, int int_bit,
             const double rinvsix_nm = rinvsq * rinvsq * rinvsq;
             const double lje2 = p->ewaldcoeff_lj * p->ewaldcoeff_lj;
             const double cr2 = lje2 * rsq, expmcr2 = exp(-cr2), poly = 1 + cr2 + 0.5 * cr2 * cr2;
-            frLJ += c6grid * (rinvsix_nm - expmcr2 * (rinvsix_nm * poly + lje2 * lje2 * lje2 / 6.0));
-            VLJ  += c6grid / 6 * (rinvsix_nm * (1 - expmcr2 * poly) + p->sh_lj_ewald * int_bit);
+            if (cr2 < 1e-2)
+            {
+                /* 1 - exp(-x)(1 + x + x^2/2) = sum_k (-1)^k x^(k+3) / (2 k! (k+3)): the reference's expression
+                 * cancels to nothing as r -> 0 (excluded atoms on one point, r^2 = 1e-12) and r^-6 then
+                 * multiplies the rounding noise; the arbiter takes the series there */
+                const double x = cr2;
+                const double one_m = x * x * x * (1.0 / 6 + x * (-1.0 / 8 + x * (1.0 / 20 + x * (-1.0 / 72 + x * (1.0 / 336 - x / 1920)))));
+                frLJ += c6grid * (rinvsix_nm * one_m - expmcr2 * lje2 * lje2 * lje2 / 6.0);
+                VLJ  += c6grid / 6 * (rinvsix_nm * one_m + p->sh_lj_ewald * int_bit);
+            }
+            else
+            {
+                frLJ += c6grid * (rinvsix_nm - expmcr2 * (rinvsix_nm * poly + lje2 * lje2 * lje2 / 6.0));
+                VLJ  += c6grid / 6 * (rinvsix_nm * (1 - expmcr2 * poly) + p->sh_lj_ewald * int_bit);
+            }
         }
         fscal += frLJ * rinvsq;
         if (vv) { *vv += VLJ; }
@@ -248,7 +261,10 @@ int oracle_kernel_gpu_list(int natoms, const float *xq, const int *type, int nty
                 for (im = 0; im < NSC; im++)
                 {
                     int within_rlist = 0;
-                    if (!((g->imei[0].imask >> (jm * NSC + im)) & 1u)) { continue; }
+                    /* nbnxn_kernel_gpu_ref.c:194-197 reads imei[0] alone (host-built lists carry the same mask twice,
+                     * nbnxn_search.c:3108-3111); a list pruned per 32-lane half on a GPU (nbnxn_cuda_kernel.cuh:503) carries
+                     * two, and a cluster pair is alive while either half keeps it: the union */
+                    if (!(((g->imei[0].imask | g->imei[1].imask) >> (jm * NSC + im)) & 1u)) { continue; }
                     {
                         const int cj = g->cj[jm];
                         const int ci = s * NSC + im;
@@ -317,7 +333,7 @@ int oracle_prune_list(const float *xq, const float *shift_vec, int nsci, const n
         const float     *sh = shift_vec + 3 * e->shift;
         for (j4 = e->cj4_ind_start; j4 < e->cj4_ind_end; j4++)
         {
-            unsigned imask = cj4[j4].imei[0].imask;
+            unsigned imask = cj4[j4].imei[0].imask | cj4[j4].imei[1].imask;   /* the union, as the wave64 kernels walk it */
             for (jm = 0; jm < NBX_JGROUP_SIZE; jm++)
             {
                 for (im = 0; im < NSC; im++)
@@ -513,7 +529,10 @@ int oracle_kernel_gpu_list_f32(int natoms, const float *xq, const int *type, int
                 for (im = 0; im < NSC; im++)
                 {
                     const int cj = g->cj[jm], ci = e->sci * NSC + im;
-                    if (!((g->imei[0].imask >> (jm * NSC + im)) & 1u)) { continue; }
+                    /* nbnxn_kernel_gpu_ref.c:194-197 reads imei[0] alone (host-built lists carry the same mask twice,
+                     * nbnxn_search.c:3108-3111); a list pruned per 32-lane half on a GPU (nbnxn_cuda_kernel.cuh:503) carries
+                     * two, and a cluster pair is alive while either half keeps it: the union */
+                    if (!(((g->imei[0].imask | g->imei[1].imask) >> (jm * NSC + im)) & 1u)) { continue; }
                     for (ic = 0; ic < CL; ic++)
                     {
                         const int   ia = ci * CL + ic;

@@ -179,6 +179,23 @@ static void free_ic(interaction_const_t *ic)
     free(ic->tabq_coul_FDV0);
 }
 
+/* The Coulomb table make_ic() hands to the reference kernels (the harness's restatement of tables.c, see the
+ * header): size and scale are returned, FDV0 [4 * size] is copied when fdv0 is non-NULL with room for it.  The tests
+ * check every point of it against the closed forms (tests/test_oracle_golden.py), so that an error in the
+ * restatement cannot hide inside a force tolerance. */
+int ref_ewald_table(const ref_params_t *p, float *scale, float *fdv0, int fdv0_alloc)
+{
+    interaction_const_t ic;
+    int                 n;
+    if (p->el_type == 0) { return 0; }
+    make_ic(p, &ic);
+    n = ic.tabq_size;
+    if (scale) { *scale = ic.tabq_scale; }
+    if (fdv0 && fdv0_alloc >= 4 * n) { memcpy(fdv0, ic.tabq_coul_FDV0, (size_t)n * 4 * sizeof(float)); }
+    free_ic(&ic);
+    return n;
+}
+
 /* nbnxn_kernel_gpu_ref on the GPU-format list.  f [natoms*3] is cleared and filled. */
 int ref_run_kernel_gpu_ref(int natoms, const float *xq, const int *type, int ntype,
                            const float *nbfp, const float *shift_vec,

@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gromacs_cosmo_amd as g  # noqa: E402
 import oracle as O             # noqa: E402
 
@@ -98,6 +99,15 @@ if __name__ == "__main__":
                 g.system.with_ljpme(g.system.ewald(0.9), g.abi.LJCR_LB), mcb=100)
     switch_case("spc648_rf09_ljpme_geom", g.system.water_box(1, 1, 1),
                 g.system.with_ljpme(g.system.reaction_field(0.9), g.abi.LJCR_GEOM))
+    # two distinct, mutually excluded atoms on one point (r = 0): the reference's r^2 increment at work
+    from util import coincident_excluded_system
+    co, _ = coincident_excluded_system()
+    small_case("ljchain1000_coincident_rf09", co, g.system.reaction_field(0.9), mcb=100)
+    small_case("ljchain1000_coincident_ewald09", co, g.system.ewald(0.9), mcb=100)
+    switch_case("ljchain1000_coincident_ewald09_fswitch07", co, g.system.with_force_switch(g.system.ewald(0.9), 0.7), mcb=100)
+    switch_case("ljchain1000_coincident_ewald09_pswitch07", co, g.system.with_potential_switch(g.system.ewald(0.9), 0.7), mcb=100)
+    switch_case("ljchain1000_coincident_ewald09_ljpme_geom", co, g.system.with_ljpme(g.system.ewald(0.9), g.abi.LJCR_GEOM), mcb=100)
+    switch_case("ljchain1000_coincident_rf09_ljpme_lb", co, g.system.with_ljpme(g.system.reaction_field(0.9), g.abi.LJCR_LB), mcb=100)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         sys.exit(0)
     large_case("spc97k_rf10", (5, 5, 6), "spc", g.system.reaction_field(1.0))

@@ -30,6 +30,11 @@ XFIELDS = ["vdw_modifier", "rvdw_switch", "disp_c2", "disp_c3", "rep_c2", "rep_c
            "vdwtype", "ljpme_comb_rule", "ewaldcoeff_lj", "sh_lj_ewald"]     # older fixtures stop at sw_c5
 SWITCH = ["spc648_rf09_fswitch07", "ljchain1000_ewald09_pswitch07", "ljchain1000_ewald09_fswitch07"]
 LJPME = ["ljchain1000_ewald09_ljpme_geom", "ljchain1000_ewald09_ljpme_lb", "spc648_rf09_ljpme_geom"]
+# two distinct, mutually excluded atoms on one point (coincident_excluded_system below); the first two also hold
+# nbnxn_kernel_gpu_ref outputs
+COINCIDENT = ["ljchain1000_coincident_rf09", "ljchain1000_coincident_ewald09", "ljchain1000_coincident_ewald09_fswitch07",
+              "ljchain1000_coincident_ewald09_pswitch07", "ljchain1000_coincident_ewald09_ljpme_geom",
+              "ljchain1000_coincident_rf09_ljpme_lb"]
 
 
 def params_from_array(arr, ext=None):
@@ -98,3 +103,29 @@ def brute_force_sample(system, ip, idx):
             fs += qq * (bit / (r2 * r) - (erf(b * r) / r - 2.0 * b / np.sqrt(np.pi) * np.exp(-b * b * r2)) / r2)
         out[n] = (fs[:, None] * d).sum(0)
     return out
+
+
+def coincident_excluded_system(natoms=1000, every=23, seed=2026):
+    """The 8-type chain mixture with every `every`-th bonded (1-2, mutually excluded) pair of atoms put on ONE point:
+    what shell / Drude particles and virtual sites on atoms look like to the kernels.  r = 0 between two DISTINCT
+    atoms is what the reference's r^2 += (1 - int_bit) * NBNXN_AVOID_SING_R2_INC exists for (nbnxn_consts.h:66-79).
+    Returns the System and the list of (k, k + 1) caller-order pairs."""
+    s = g.system.lj_chain_mixture(natoms, ntype=8, seed=seed)
+    x = s.x.copy()
+    pairs = []
+    for k in range(5, natoms - 1, every):
+        if k + 1 in s.excl_a[s.excl_index[k]:s.excl_index[k + 1]]:
+            x[k + 1] = x[k]
+            pairs.append((k, k + 1))
+    s.x = x
+    s.name = f"ljchain{natoms}_coincident"
+    return s, pairs
+
+
+def ljpme_grid_c6(nbfp, ntype, comb_rule, ti, tj):
+    """grid C6 of a type pair as the kernels combine it (nbnxn_kernel_ref_inner.h:211-226)"""
+    c = g.system.nbfp_comb(nbfp, ntype, comb_rule).astype(np.float64)
+    if comb_rule == abi.LJCR_GEOM:
+        return c[ti, 0] * c[tj, 0]
+    sigma, eps = c[ti, 0] + c[tj, 0], c[ti, 1] * c[tj, 1]
+    return eps * sigma ** 6
