@@ -134,6 +134,10 @@ struct nbnxn_hip {
 
     PList plist[2];
 
+    // kernel-ready constants (nbnxn_kernel.h), derived from the parameters above when they change, not per launch
+    nbx_kernel_k_t kc;
+    bool           kc_valid = false;
+
     // pinned staging for the small outputs (nb_staging, nbnxn_cuda_types.h:104-110)
     float *fbase   = nullptr;   // one allocation: 2 x {[out slots][f]}, so one memset clears slots and forces
     // In-kernel clear (nbnxn_hip_set_clear_in_kernel): the two halves of fbase alternate as the
@@ -271,6 +275,7 @@ int set_params(nbnxn_hip *nb, int el_type, float rcoulomb, float rvdw, float rli
     // (nbnxn_cuda_data_mgmt.cu:597-606)
     if (el_type == NBX_EL_EWALD_TAB && upload_coulomb_tab(nb, beta, rcoulomb)) { return 1; }
     nb->have_const = true;
+    nb->kc_valid   = false;
     return 0;
 }
 
@@ -429,6 +434,60 @@ int init_atomdata_impl(nbnxn_hip *nb, int natoms, int natoms_local, int ntype, c
     return 0;
 }
 
+// Kernel-ready constants (nbnxn_kernel.h: nbx_kernel_k_t), rounded once from double.  They change with
+// init_const / set_vdw_modifier / set_ljpme / pme_loadbal_update_param only, so the ~25 pow / divisions are
+// spent there (kc_valid) and a launch copies the struct and sets the one value that belongs to the list.
+void compute_kernel_consts(const nbnxn_hip *nb, nbx_kernel_k_t &k)
+{
+    const bool   ew = (nb->el_type != NBX_EL_RF);
+    const double b  = ew ? (double)nb->beta : 1.0;
+    k.xscale   = (float)b;
+    k.qscale   = (float)((double)nb->epsfac * b * b);
+    k.c6scale  = (float)std::pow(b, 7);
+    k.c12scale = (float)std::pow(b, 13);
+    k.escale   = (float)(1.0 / b);
+    k.rc2      = (float)(b * b * (double)nb->rcoulomb * (double)nb->rcoulomb);
+    k.rlist2   = 0;   // belongs to the list: fill_kernel_consts
+    k.rvdw2    = (float)(b * b * (double)nb->rvdw * (double)nb->rvdw);
+    k.r2inc    = (float)(b * b * (double)NBX_AVOID_SING_R2_INC);
+    // switch constants in scaled units: rsw' = beta rsw; a force-switch term c6' (c2 + c3 rsw') rsw'^2 / r'
+    // with c6' = c6 beta^7 must equal (true term) / beta, which gives c2 / beta^9, c3 / beta^10 for
+    // dispersion and c2 / beta^15, c3 / beta^16 for repulsion; potential switch c_n / beta^n
+    k.vdw_rsw = (float)(b * (double)nb->rvdw_switch);
+    k.fsw_d2  = (float)((double)nb->fsw[0] / std::pow(b, 9));
+    k.fsw_d3  = (float)((double)nb->fsw[1] / std::pow(b, 10));
+    k.fsw_r2  = (float)((double)nb->fsw[2] / std::pow(b, 15));
+    k.fsw_r3  = (float)((double)nb->fsw[3] / std::pow(b, 16));
+    k.psw_c3  = (float)((double)nb->psw[0] / std::pow(b, 3));
+    k.psw_c4  = (float)((double)nb->psw[1] / std::pow(b, 4));
+    k.psw_c5  = (float)((double)nb->psw[2] / std::pow(b, 5));
+    k.sh       = (float)((double)nb->sh_ewald / b);
+    k.rep12    = (float)((double)nb->rep_cpot / 12.0 / std::pow(b, 12));
+    k.ndisp6   = (float)(-(double)nb->disp_cpot / 6.0 / std::pow(b, 6));
+    // E_self = -c q_raw^2 epsfac with c = c_rf / 2 | beta / sqrt(pi); the kernel has q' = qscale q_raw
+    // and multiplies the sum by escale at the end
+    // LJ-PME: cl = ewaldcoeff_lj in scaled units
+    const double cl = (double)nb->ewaldcoeff_lj / b;
+    k.lje2        = (float)(cl * cl);
+    k.lje2_nlog2e = (float)(-cl * cl * 1.4426950408889634);
+    k.lje6_6      = (float)(std::pow(cl, 6) / 6.0);
+    k.lje_sh6     = (float)((double)nb->sh_lj_ewald / std::pow(b, 6) / 6.0);
+    k.tab_scale   = (float)((double)nb->tab_scale / b);
+    k.tab_max     = (float)(nb->tab_size - 2);
+    const double cself = ew ? (double)nb->beta * 0.5641895835477563 : 0.5 * (double)nb->c_rf;
+    k.two_k_rf = 2 * nb->k_rf;
+    k.c_rf     = nb->c_rf;
+    k.self     = (float)(-cself * (double)nb->epsfac / ((double)k.qscale * (double)k.qscale) * b);
+}
+
+void fill_kernel_consts(nbnxn_hip *nb, float rlist, nbx_kernel_k_t &k)
+{
+    if (!nb->kc_valid) { compute_kernel_consts(nb, nb->kc); nb->kc_valid = true; }
+    k = nb->kc;
+    const double b = (nb->el_type != NBX_EL_RF) ? (double)nb->beta : 1.0;
+    k.rlist2 = (float)(b * b * (double)rlist * (double)rlist);
+}
+
 int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
 {
     if (check_loc(iloc)) { return 1; }
@@ -471,48 +530,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
         a.zero    = reinterpret_cast<float4 *>(nb->fbase + (size_t)(1 - nb->cur) * nb->half_floats);
         a.zero_n4 = (int)((OUT_FLOATS + (size_t)nb->natoms * 3 + 3) / 4);
     }
-    {
-        // kernel-ready constants (nbnxn_kernel.h: nbx_kernel_k_t), rounded once from double
-        const bool   ew = (nb->el_type != NBX_EL_RF);
-        const double b  = ew ? (double)nb->beta : 1.0;
-        a.k.xscale   = (float)b;
-        a.k.qscale   = (float)((double)nb->epsfac * b * b);
-        a.k.c6scale  = (float)std::pow(b, 7);
-        a.k.c12scale = (float)std::pow(b, 13);
-        a.k.escale   = (float)(1.0 / b);
-        a.k.rc2      = (float)(b * b * (double)nb->rcoulomb * (double)nb->rcoulomb);
-        a.k.rlist2   = (float)(b * b * (double)pl.rlist * (double)pl.rlist);
-        a.k.rvdw2    = (float)(b * b * (double)nb->rvdw * (double)nb->rvdw);
-        a.k.r2inc    = (float)(b * b * (double)NBX_AVOID_SING_R2_INC);
-        // switch constants in scaled units: rsw' = beta rsw; a force-switch term c6' (c2 + c3 rsw') rsw'^2 / r'
-        // with c6' = c6 beta^7 must equal (true term) / beta, which gives c2 / beta^9, c3 / beta^10 for
-        // dispersion and c2 / beta^15, c3 / beta^16 for repulsion; potential switch c_n / beta^n
-        a.k.vdw_rsw = (float)(b * (double)nb->rvdw_switch);
-        a.k.fsw_d2  = (float)((double)nb->fsw[0] / std::pow(b, 9));
-        a.k.fsw_d3  = (float)((double)nb->fsw[1] / std::pow(b, 10));
-        a.k.fsw_r2  = (float)((double)nb->fsw[2] / std::pow(b, 15));
-        a.k.fsw_r3  = (float)((double)nb->fsw[3] / std::pow(b, 16));
-        a.k.psw_c3  = (float)((double)nb->psw[0] / std::pow(b, 3));
-        a.k.psw_c4  = (float)((double)nb->psw[1] / std::pow(b, 4));
-        a.k.psw_c5  = (float)((double)nb->psw[2] / std::pow(b, 5));
-        a.k.sh       = (float)((double)nb->sh_ewald / b);
-        a.k.rep12    = (float)((double)nb->rep_cpot / 12.0 / std::pow(b, 12));
-        a.k.ndisp6   = (float)(-(double)nb->disp_cpot / 6.0 / std::pow(b, 6));
-        // E_self = -c q_raw^2 epsfac with c = c_rf / 2 | beta / sqrt(pi); the kernel has q' = qscale q_raw
-        // and multiplies the sum by escale at the end
-        // LJ-PME: cl = ewaldcoeff_lj in scaled units
-        const double cl = (double)nb->ewaldcoeff_lj / b;
-        a.k.lje2        = (float)(cl * cl);
-        a.k.lje2_nlog2e = (float)(-cl * cl * 1.4426950408889634);
-        a.k.lje6_6      = (float)(std::pow(cl, 6) / 6.0);
-        a.k.lje_sh6     = (float)((double)nb->sh_lj_ewald / std::pow(b, 6) / 6.0);
-        a.k.tab_scale   = (float)((double)nb->tab_scale / b);
-        a.k.tab_max     = (float)(nb->tab_size - 2);
-        const double cself = ew ? (double)nb->beta * 0.5641895835477563 : 0.5 * (double)nb->c_rf;
-        a.k.two_k_rf = 2 * nb->k_rf;
-        a.k.c_rf     = nb->c_rf;
-        a.k.self     = (float)(-cself * (double)nb->epsfac / ((double)a.k.qscale * (double)a.k.qscale) * b);
-    }
+    fill_kernel_consts(nb, pl.rlist, a.k);
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
     HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->rvdw < nb->rcoulomb, nb->vdw_mod, st));
@@ -739,6 +757,7 @@ int nbnxn_hip_init_const_flat(nbnxn_hip_ptr_t nb, int el_type, float rcoulomb, f
     HIP_TRY(hipSetDevice(nb->device));
     if (set_params(nb, el_type, rcoulomb, rvdw, rlist, epsfac, k_rf, c_rf, ewaldcoeff_q, sh_ewald, disp_cpot, rep_cpot)) { return 1; }
     nb->vdw_mod = 0; nb->rvdw_switch = 0;   // plain cut-off until nbnxn_hip_set_vdw_modifier_flat says otherwise
+    nb->kc_valid = false;
     if (upload_nbfp(nb, ntype, nbfp)) { return 1; }
     if (clear_e_fshift(nb)) { return 1; }
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
@@ -761,6 +780,7 @@ int nbnxn_hip_set_vdw_modifier_flat(nbnxn_hip_ptr_t nb, int vdw_modifier, float 
         return nbx_fail("rvdw_switch (%g) must be in [0, rvdw = %g)", rvdw_switch, nb->rvdw);
     }
     nb->vdw_mod     = mod;
+    nb->kc_valid    = false;
     nb->rvdw_switch = mod ? rvdw_switch : 0.0f;
     nb->fsw[0] = disp_c2; nb->fsw[1] = disp_c3; nb->fsw[2] = rep_c2; nb->fsw[3] = rep_c3;
     nb->psw[0] = sw_c3; nb->psw[1] = sw_c4; nb->psw[2] = sw_c5;
@@ -796,6 +816,7 @@ int nbnxn_hip_set_ljpme_flat(nbnxn_hip_ptr_t nb, int comb_rule, float ewaldcoeff
     HIP_TRY(hipMemcpyAsync(nb->c6grid.p, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, nb->stream[0]));
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
     nb->vdw_mod       = 3;
+    nb->kc_valid      = false;
     nb->rvdw_switch   = 0;
     nb->ewaldcoeff_lj = ewaldcoeff_lj;
     nb->sh_lj_ewald   = sh_lj_ewald;

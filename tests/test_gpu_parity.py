@@ -726,7 +726,7 @@ def test_list_quirks_of_the_reference_builders(nb):
     nbnxn_cuda_kernel.cuh:332-340, :503).  A wave64 walks the union; both against the oracle on the same list."""
     from gromacs_cosmo_amd.host import PairList
     rng = np.random.default_rng(17)
-    for ip, s in ((g.system.ewald(0.9, rlist=1.0), g.system.water_box(3, 1, 1, model="spce")),
+    for ip, s in ((g.system.ewald(0.9, rlist=1.0), g.system.water_box(2, 2, 2, model="spce")),
                   (g.system.reaction_field(0.9, rlist=1.0), g.system.lj_chain_mixture(3000))):
         p = g.workload.prepare(s, ip, 150)
         cj4 = p.pl.cj4.copy()
