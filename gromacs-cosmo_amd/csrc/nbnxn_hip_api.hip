@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,47 @@ struct PList {
     int                rolling_part = 0, rolling_nparts = 0;
 };
 
+} // namespace
+
+// ---- the entry point that allocates nothing (nbnxn_hip_launch_kernel_noalloc) ----
+// Its kernels need the same scratch buffer the other launches get from the handle's allocation: the NBX_OUT_SLOTS
+// partial-sum slots {e_lj, e_el, fshift[45][3]} that the waves add into and a fold kernel sums.  Here they live in a
+// file-scope device array: 64 x 144 floats = 36,864 bytes, whatever the system size, held by every GPU the library
+// runs on until the process ends.  `scratch` is a host-side stand-in for the symbol, NOT a device address: host
+// code only ever uses the per-device address hipGetSymbolAddress returned (g_scratch_ptr), as kernel argument and
+// for the clearing fill.
+#define NBX_NOALLOC_SCRATCH_FLOATS (NBX_OUT_SLOTS * NBX_OUT_STRIDE)
+#define NBX_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[NBX_NOALLOC_SCRATCH_FLOATS];
+
+namespace {
+float     *g_scratch_ptr[NBX_MAX_DEVICES] = {};   // each GPU has its own copy of the array at its own address
+std::mutex g_scratch_mutex;
+
+// once per device, with that device current (nbnxn_hip_init calls it right after hipSetDevice)
+int bind_scratch(int device)
+{
+    if (device < 0 || device >= NBX_MAX_DEVICES) { return nbx_fail("device %d outside [0, %d)", device, NBX_MAX_DEVICES); }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) { return 0; }
+    float *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) { return nbx_fail("hipGetSymbolAddress returned no address for the scratch array on device %d", device); }
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
+
+// sums the slots in double, as fold_outputs does on the host, and ASSIGNS {e_lj, e_el, fshift[45][3]} to out
+__global__ void nbx_fold_slots_kernel(const float *__restrict__ slots, float *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k < 2 + NBX_SHIFTS * 3)
+    {
+        double sum = 0;
+        for (int s = 0; s < NBX_OUT_SLOTS; s++) { sum += (double)slots[s * NBX_OUT_STRIDE + k]; }
+        out[k] = (float)sum;
+    }
+}
 } // namespace
 
 struct nbnxn_hip {
@@ -678,6 +720,7 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     {
         return nbx_fail("device %d is %s; this library carries gfx950 (MI355X) code objects only", device_id, prop.gcnArchName);
     }
+    if (bind_scratch(device_id)) { return 1; }
     nbnxn_hip *nb = new nbnxn_hip();
     nb->device      = device_id;
     nb->two_streams = bLocalAndNonlocal != 0;
@@ -1022,6 +1065,52 @@ int nbnxn_hip_launch_kernel_resident(nbnxn_hip_ptr_t nb, int flags, int iloc)
     if (check_handle(nb)) { return 1; }
     HIP_TRY(hipSetDevice(nb->device));
     return launch_impl(nb, nullptr, flags, iloc);
+}
+
+int nbnxn_hip_launch_kernel_noalloc(nbnxn_hip_ptr_t nb, int flags, int iloc, int natoms, const float *d_xq, float *d_f,
+                                    float *d_e_fshift)
+{
+    if (check_handle(nb) || check_loc(iloc)) { return 1; }
+    if (!nb->have_const) { return nbx_fail("launch before init_const"); }
+    if (!nb->shift_vec_uploaded) { return nbx_fail("launch before upload_shiftvec"); }
+    const bool ener = (flags & NBX_FORCE_VIRIAL) != 0;
+    if (natoms > NBX_NOALLOC_MAX_ATOMS)
+    {
+        return nbx_fail("launch_kernel_noalloc: %d atoms exceed the maximum of %d this entry point takes", natoms, NBX_NOALLOC_MAX_ATOMS);
+    }
+    if (natoms != nb->natoms) { return nbx_fail("launch_kernel_noalloc: %d atoms passed, the installed atom data and list are for %d", natoms, nb->natoms); }
+    if (!d_xq || !d_f || (ener && !d_e_fshift)) { return nbx_fail("launch_kernel_noalloc: null coordinate, force or energy array"); }
+    PList &pl = nb->plist[iloc];
+    if (pl.nsci == 0) { return 0; }
+    if (pl.nsci > NBX_NOALLOC_MAX_NSCI)
+    {
+        return nbx_fail("launch_kernel_noalloc: %d list entries exceed the maximum of %d this entry point takes", pl.nsci, NBX_NOALLOC_MAX_NSCI);
+    }
+    float *slots = g_scratch_ptr[nb->device];
+    if (!slots) { return nbx_fail("launch_kernel_noalloc: the scratch array of device %d was never bound", nb->device); }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = nb->stream[iloc];
+
+    nbx_kernel_args_t a;
+    a.xq = reinterpret_cast<const float4 *>(d_xq); a.f = d_f; a.type = nb->type.p; a.shift_vec = nb->shift_vec; a.ntype = nb->ntype;
+    a.nbfp = nb->nbfp.p; a.c6grid = nb->c6grid.p; a.coulomb_tab = nb->coulomb_tab.p;
+    if (nb->vdw_mod == 3 && !a.c6grid) { return nbx_fail("LJ-PME launch without the grid C6 table"); }
+    if (nb->el_type == NBX_EL_EWALD_TAB && !a.coulomb_tab) { return nbx_fail("tabulated Ewald launch without the force table"); }
+    a.sci = pl.sci.p; a.cj4 = pl.cj4.p; a.excl = pl.excl.p;
+    a.out = slots;              // the device address from hipGetSymbolAddress, never the symbol's name
+    a.zero = nullptr; a.zero_n4 = 0;
+    fill_kernel_consts(nb, pl.rlist, a.k);
+    // the array keeps what the last call on this GPU left in it
+    if (ener) { HIP_TRY(hipMemsetAsync(slots, 0, NBX_NOALLOC_SCRATCH_FLOATS * sizeof(float), st)); }
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->rvdw < nb->rcoulomb, nb->vdw_mod, st));
+    if (ener)
+    {
+        hipLaunchKernelGGL(nbx_fold_slots_kernel, dim3(1), dim3(192), 0, st, slots, d_e_fshift);
+        HIP_TRY(hipGetLastError());
+    }
+    // the list was pruned by this launch; launches after it on this stream see the pruned masks
+    pl.do_prune = false;
+    return 0;
 }
 
 int nbnxn_hip_launch_cpyback_flat(nbnxn_hip_ptr_t nb, float *f, int flags, int aloc)

@@ -83,6 +83,7 @@ def load():
     lib.nbnxn_hip_launch_kernel.argtypes = [vp, C.POINTER(abi.Atomdata), ci, ci]
     lib.nbnxn_hip_launch_kernel_flat.argtypes = [vp, vp, ci, ci]
     lib.nbnxn_hip_launch_kernel_resident.argtypes = [vp, ci, ci]
+    lib.nbnxn_hip_launch_kernel_noalloc.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     lib.nbnxn_hip_launch_cpyback.argtypes = [vp, C.POINTER(abi.Atomdata), ci, ci]
     lib.nbnxn_hip_launch_cpyback_flat.argtypes = [vp, vp, ci, ci]
     lib.nbnxn_hip_wait_gpu.argtypes = [vp, C.POINTER(abi.Atomdata), ci, ci, vp, vp, vp]
@@ -449,6 +450,12 @@ class NbnxnHip:
 
     def launch_kernel_resident(self, flags, iloc=abi.LOCAL):
         self._chk(self.lib.nbnxn_hip_launch_kernel_resident(self.h, flags, iloc))
+
+    def launch_kernel_noalloc(self, flags, natoms, d_xq, d_f, d_e_fshift=None, iloc=abi.LOCAL):
+        """the entry point that allocates nothing: device addresses (ints) of the caller's xq [natoms, 4],
+        f [natoms, 3] (added into) and, with FORCE_VIRIAL, e_fshift [137] (assigned)"""
+        self._chk(self.lib.nbnxn_hip_launch_kernel_noalloc(self.h, flags, iloc, natoms, C.c_void_p(d_xq), C.c_void_p(d_f),
+                                                           C.c_void_p(d_e_fshift) if d_e_fshift else None))
 
     def launch_cpyback(self, f, flags, aloc=abi.LOCAL):
         assert f.dtype == np.float32 and f.shape == (self.natoms, 3) and f.flags.c_contiguous

@@ -645,6 +645,31 @@ int nbnxn_hip_set_clear_in_kernel(nbnxn_hip_ptr_t nb, int on);
  * (~7 us of device time on MI355X), so resident callers that launch every ~100 us turn it off. */
 int nbnxn_hip_set_timing(nbnxn_hip_ptr_t nb, int on);
 
+/* ---- the entry point that allocates nothing ----
+ * No counterpart in the reference.  It is for callers that cannot call hipMalloc: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid allocation.  A variant of nbnxn_hip_launch_kernel_resident: the same
+ * kernel over the pair list, atom types and parameters installed in the handle (by init_const / init_atomdata /
+ * init_pairlist or the device search, which do allocate and come before), on the handle's stream of `iloc`, but
+ *   - coordinates are read from the CALLER's device array d_xq [natoms][4] {x, y, z, q} in grid order,
+ *   - forces are ADDED into the caller's device array d_f [natoms][3] (the caller clears it),
+ *   - with NBX_FORCE_VIRIAL in flags, {e_lj, e_el, fshift[45][3]} (137 floats) are ASSIGNED to the caller's device
+ *     array d_e_fshift; without it that array is not touched and may be NULL,
+ * and the kernel's scratch buffer -- the 64 x 144-float partial-sum slots the waves add into, which every other
+ * launch takes from the handle's allocation -- is a file-scope device array of the library: 36,864 bytes per GPU,
+ * held until the process ends, whatever the system size.  The call issues one fill of that array, the kernel and a
+ * 137-thread fold kernel; it calls no hipMalloc / hipFree / allocating routine and returns without synchronising
+ * (order later work after it on nbnxn_hip_get_stream(nb, iloc), or synchronise that stream).
+ * Limits, refused with an error: natoms must equal the installed atom count and be <= NBX_NOALLOC_MAX_ATOMS, the
+ * installed list may have at most NBX_NOALLOC_MAX_NSCI entries (32-bit indexing inside the kernels; the scratch
+ * array itself does not grow with the system).  Every call on one GPU shares that GPU's array, which keeps the last
+ * call's contents (the call clears it first): calls that overlap on one GPU -- two handles, or both localities of
+ * one handle on different streams -- race on the energies; forces are unaffected.  A fresh list is pruned by this
+ * launch as by any other (the handle's list masks are rewritten in place). */
+#define NBX_NOALLOC_MAX_ATOMS (1 << 28)
+#define NBX_NOALLOC_MAX_NSCI  (1 << 30)
+int nbnxn_hip_launch_kernel_noalloc(nbnxn_hip_ptr_t nb, int flags, int iloc, int natoms, const float *d_xq, float *d_f,
+                                    float *d_e_fshift);
+
 /* kernel tuning knob for benchmarking: 0 = default variant */
 int nbnxn_hip_set_kernel_variant(nbnxn_hip_ptr_t nb, int variant);
 
