@@ -19,6 +19,15 @@
 
 #include "nbnxn_kernel.h"
 
+#ifdef NBX_TIMELINE
+// debug builds only (make timeline): per list entry {start, end} in 100 MHz ticks and the hardware id of the wave
+__device__ unsigned long long nbx_timeline[3 * 65536];
+extern "C" int nbnxn_hip_debug_timeline(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbx_timeline), sizeof(unsigned long long) * 3 * (size_t)(n < 65536 ? n : 65536)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 namespace {
 
 
@@ -166,12 +175,17 @@ __device__ __forceinline__ float wave_sum(float v)
 
 constexpr int MAX_LDS_TYPES = NBX_KERNEL_MAX_LDS_TYPES;
 
-// A third per-type-pair value rides with {c6, c12} in two flavours: the grid C6 of LJ-PME, and, for the plain
-// cut-off energy kernels, 12 x the potential-shift term c12 rep_cpot / 12 - c6 disp_cpot / 6, which would
-// otherwise cost two instructions per PAIR (the LJ energy is then accumulated as 12 E and scaled once per wave).
-constexpr bool has_third(int vmod, bool ener) { return vmod == 3 || (vmod == 0 && ener); }
+// A third per-type-pair value rides with {c6, c12} for LJ-PME: the grid C6.
+constexpr bool has_third(int vmod, bool) { return vmod == 3; }
 // bytes per type pair in the LDS parameter table: {c6, c12} or {c6, c12, third, -}
 constexpr int lds_entry_bytes(int vmod, bool ener) { return has_third(vmod, ener) ? 16 : 8; }
+
+// Energy accumulators of a lane.  The plain cut-off flavours sum the potential-shift terms apart from the pair
+// energies: s12 / s6 = sum of c12 / c6 and sq = sum of the charge products over the pairs that are inside the
+// cut-off and not excluded; the constants (rep_cpot, disp_cpot, sh_ewald) multiply the wave's sums once.
+struct nbx_eacc_t {
+    float lj = 0, el = 0, s12 = 0, s6 = 0, sq = 0;
+};
 
 // j-forces are not sent to memory one cluster at a time: on CDNA the wave's loads, stores
 // and atomics retire in order through one counter (vmcnt), so a load issued after an atomic
@@ -222,7 +236,7 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
                                         const float2 c, const float c6g, const unsigned wexcl, const int bitpos, const bool allowed,
                                         const float r2inc,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
-                                        float &E_lj, float &E_el, bool &any_in_rlist)
+                                        nbx_eacc_t &acc, bool &any_in_rlist)
 {
     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
     // 0 for an excluded pair, all ones otherwise
@@ -240,6 +254,54 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     if (PRUNE) { any_in_rlist = __any(r2 < a.k.rlist2); }
     const bool  cond = (r2 < a.k.rc2) && allowed;
     const float inv_r  = __builtin_amdgcn_rsqf(r2);
+    if (VMOD == 0 && !VDWC && ENER)
+    {
+        // The energy kernels of the plain cut-off flavours (the headline configuration).  The exclusion mask goes onto
+        // 1/r ONCE: r^-2, r^-6, the LJ force and energy and the plain Coulomb term then vanish for excluded pairs by
+        // themselves.  The cut-off is a 0 / 1 factor: one select, and the two energy adds become fused multiply-adds.
+        // The potential-shift constants do not enter here at all (nbx_eacc_t).  55 instructions per pair for
+        // analytical Ewald where masking the results and selecting each of them took 60.
+        const float inv_rm = and_mask(inv_r, m);
+        const float u2     = inv_rm * inv_rm;
+        const float u6     = u2 * u2 * u2;
+        const float qq     = xi.w * xj.w;
+        const float lj6    = u6 * fmaf(c.y, u6, -c.x);              // F_lj * r = c12 r^-12 - c6 r^-6
+        const float t      = fmaf(qq, inv_rm, lj6) * u2;
+        float       F, ec;
+        if (EL == NBX_EL_RF)
+        {
+            F  = fmaf(qq, -a.k.two_k_rf, t);
+            ec = inv_rm + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf);   // c_rf also goes with excluded pairs
+        }
+        else
+        {
+            // the cut-off acts as a FACTOR below, so what it discards must be finite: filler atoms sit thousands of nm
+            // away, where the fits' polynomials overflow.  The fits hold on [0, 16]; beyond rc the value is not used
+            float gf, gv;
+            pme_corr_fv(fminf(r2, 16.0f), gf, gv);
+            if (EL == NBX_EL_EWALD_TAB)
+            {
+                const float rs  = fminf(r2 * inv_r * a.k.tab_scale, a.k.tab_max);
+                const int   idx = (int)rs;
+                const float fr  = rs - (float)idx;
+                const float t0  = a.tab[idx], t1 = a.tab[idx + 1];
+                F = fmaf(qq, -fmaf(fr, t1, fmaf(-fr, t0, t0)) * inv_r, t);
+            }
+            else { F = fmaf(qq, gf, t); }
+            ec = inv_rm - gv;
+        }
+        const float wc = cond ? 1.0f : 0.0f;
+        const float ws = and_mask(wc, m);
+        F *= wc;
+        acc.lj  = fmaf(fmaf(-c.x, u6, lj6), wc, acc.lj);             // 12 x [c12 r^-12 / 12 - c6 r^-6 / 6]
+        acc.s12 = fmaf(c.y, ws, acc.s12);
+        acc.s6  = fmaf(c.x, ws, acc.s6);
+        acc.el  = fmaf(qq * wc, ec, acc.el);
+        if (EL != NBX_EL_RF) { acc.sq = fmaf(qq, ws, acc.sq); }
+        fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
+        fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
+        return;
+    }
     const float inv_r2 = inv_r * inv_r;
     const float inv_r6 = inv_r2 * inv_r2 * inv_r2;
     // twin-range flavour (VDW_CUTOFF_CHECK, nbnxn_cuda_kernel.cuh:405-409, 436-441): rvdw < rcoulomb
@@ -255,9 +317,9 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
         t = and_mask(fmaf(qq, inv_r, lj6v) * inv_r2, m);
         if (ENER)
         {
-            // 12 x [c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6] = lj6 - c6 r^-6 + c6g, with c6g = 12 x the
-            // shift term of the type pair (has_third); the 1/12 is applied to the wave's sum
-            elj = and_mask(fmaf(-c.x, inv_r6, lj6 + c6g), m);
+            // (twin-range flavours only: the others returned above) 12 x [c12 (r^-12 + rep_cpot) / 12 - c6 (r^-6 + disp_cpot) / 6];
+            // the 1/12 is applied to the wave's sum
+            elj = and_mask(fmaf(-c.x, inv_r6, lj6 + 12.0f * fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6)), m);
         }
     }
     else if (VMOD == 3)
@@ -347,8 +409,8 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
         float eel;
         if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf)); }
         else { eel = qq * (and_mask(inv_r - a.k.sh, m) - gv); }
-        E_lj += cond ? elj : 0.0f;
-        E_el += cond ? eel : 0.0f;
+        acc.lj += cond ? elj : 0.0f;
+        acc.el += cond ? eel : 0.0f;
     }
     fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
     fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
@@ -395,7 +457,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
                                             const nbx_jslot_t &s, const int cj, const unsigned wexcl,
                                             unsigned &imask, const bool central, const int sci, const int tidxi,
                                             const int tidxj, const int lane, const float2 *s_nbfp, float *s_fj,
-                                            int *s_fjc, int &nfj, float &E_lj, float &E_el, const float ox, const float oy,
+                                            int *s_fjc, int &nfj, nbx_eacc_t &acc, const float ox, const float oy,
                                             const float oz)
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
@@ -433,7 +495,6 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
             c[i]  = a.nbfp[tb * a.ntype + s.t];
             cg[i] = VMOD == 3 ? a.c6grid[tb * a.ntype + s.t] : 0.0f;
             if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; cg[i] *= a.k.c6scale; }
-            if (VMOD == 0 && ENER) { cg[i] = 12.0f * fmaf(c[i].y, a.k.rep12, c[i].x * a.k.ndisp6); }
         }
     }
     float4 xj = s.x;
@@ -449,7 +510,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
             pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, a.k.r2inc,
-                                                 fix[i], fiy[i], fiz[i], fjx, fjy, fjz, E_lj, E_el, any);
+                                                 fix[i], fiy[i], fiz[i], fjx, fjy, fjz, acc, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
     }
@@ -486,6 +547,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     __shared__ int    s_fjc[FJ_CAP];
     int               nfj = 0;
 
+#ifdef NBX_TIMELINE
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const nbx_sci_t e     = a.sci[blockIdx.x];
     const int       sci   = e.sci;
     const int       ntype = a.ntype;
@@ -521,7 +585,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
                 char *entry = reinterpret_cast<char *>(s_nbfp) + (t_j * MAX_LDS_TYPES + t_i) * TS;
                 *reinterpret_cast<float2 *>(entry) = c;
                 if (VMOD == 3) { *reinterpret_cast<float *>(entry + 8) = a.c6grid[k] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
-                if (VMOD == 0 && ENER) { *reinterpret_cast<float *>(entry + 8) = 12.0f * fmaf(c.y, a.k.rep12, c.x * a.k.ndisp6); }
             }
         }
     }
@@ -557,14 +620,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
     }
 
-    float E_lj = 0, E_el = 0;
+    nbx_eacc_t acc;
     if (ENER)
     {
         if (central && e.cj4_ind_end > e.cj4_ind_start && a.cj4[e.cj4_ind_start].cj[0] == sci * 8)
         {
             // self term (nbnxn_cuda_kernel.cuh:239-262) in the scaled charges
             const float q = s_xqi[lane].w;
-            E_el = a.k.self * q * q;
+            acc.el = a.k.self * q * q;
             if (VMOD == 3)
             {
                 // LJ-PME self term: 0.5 * C6_ii / 6 * cl^6 / 6 per atom (nbnxn_cuda_kernel.cuh:232-246)
@@ -572,7 +635,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
                 float     c6ii;
                 if (NBFP_LDS) { c6ii = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_nbfp) + (ti * MAX_LDS_TYPES + ti) * TS); }
                 else { c6ii = a.nbfp[ti * ntype + ti].x * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
-                E_lj = c6ii * (0.5f / 6.0f) * a.k.lje6_6;
+                acc.lj = c6ii * (0.5f / 6.0f) * a.k.lje6_6;
             }
         }
     }
@@ -580,7 +643,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 #define NBX_JCLUSTER(JM, SLOT)                                                                             \
     jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
-                                               nfj, E_lj, E_el, ox, oy, oz)
+                                               nfj, acc, ox, oy, oz)
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
     {
         // software pipeline: the next group's list words are requested before this group's
@@ -648,13 +711,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         atomicAdd(&fi[lane + 128], s_red[lane + 128]);
     }
 
+#ifdef NBX_TIMELINE
+    if (lane == 0 && blockIdx.x < 65536)
+    {
+        unsigned hwid;
+        __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        nbx_timeline[3 * blockIdx.x]     = tl_t0;
+        nbx_timeline[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        nbx_timeline[3 * blockIdx.x + 2] = hwid | ((unsigned long long)(e.cj4_ind_end - e.cj4_ind_start) << 32);
+    }
+#endif
     if (ENER)
     {
         const float sx = central ? 0.0f : wave_sum(rx);
         const float sy = central ? 0.0f : wave_sum(ry);
         const float sz = central ? 0.0f : wave_sum(rz);
-        E_lj = wave_sum(E_lj) * a.k.escale * (VMOD == 0 ? 1.0f / 12.0f : 1.0f);
-        E_el = wave_sum(E_el) * a.k.escale;
+        if (VMOD == 0 && !VDWC)
+        {
+            // the potential-shift terms, from the sums over the pairs they go with (nbx_eacc_t)
+            acc.lj = fmaf(12.0f, fmaf(acc.s12, a.k.rep12, acc.s6 * a.k.ndisp6), acc.lj);
+            if (EL != NBX_EL_RF) { acc.el = fmaf(-a.k.sh, acc.sq, acc.el); }
+        }
+        const float E_lj = wave_sum(acc.lj) * a.k.escale * (VMOD == 0 ? 1.0f / 12.0f : 1.0f);
+        const float E_el = wave_sum(acc.el) * a.k.escale;
         // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
         float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
         if (lane < 3)
