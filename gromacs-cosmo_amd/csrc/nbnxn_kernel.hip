@@ -538,7 +538,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 
     __shared__ float4 s_xqi[64];
     __shared__ int    s_ti[64];
-    __shared__ float  s_red[192];
     // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
     constexpr int     TS = lds_entry_bytes(VMOD, ENER);
     __shared__ __attribute__((aligned(16))) float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES * (TS / 8) : 1];
@@ -677,38 +676,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 #undef NBX_JCLUSTER
     if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
 
-    float rx, ry, rz;
-    {
-        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-        float      gx[4], gy[4], gz[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            gx[k] = (h5 ? fix[k + 4] : fix[k]) + __shfl_xor(h5 ? fix[k] : fix[k + 4], 32);
-            gy[k] = (h5 ? fiy[k + 4] : fiy[k]) + __shfl_xor(h5 ? fiy[k] : fiy[k + 4], 32);
-            gz[k] = (h5 ? fiz[k + 4] : fiz[k]) + __shfl_xor(h5 ? fiz[k] : fiz[k + 4], 32);
-        }
-        float hx[2], hy[2], hz[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-        {
-            hx[k] = (h4 ? gx[k + 2] : gx[k]) + __shfl_xor(h4 ? gx[k] : gx[k + 2], 16);
-            hy[k] = (h4 ? gy[k + 2] : gy[k]) + __shfl_xor(h4 ? gy[k] : gy[k + 2], 16);
-            hz[k] = (h4 ? gz[k + 2] : gz[k]) + __shfl_xor(h4 ? gz[k] : gz[k + 2], 16);
-        }
-        rx = (h3 ? hx[1] : hx[0]) + __shfl_xor(h3 ? hx[0] : hx[1], 8);
-        ry = (h3 ? hy[1] : hy[0]) + __shfl_xor(h3 ? hy[0] : hy[1], 8);
-        rz = (h3 ? hz[1] : hz[0]) + __shfl_xor(h3 ? hz[0] : hz[1], 8);
-    }
-    s_red[lane * 3 + 0] = rx;
-    s_red[lane * 3 + 1] = ry;
-    s_red[lane * 3 + 2] = rz;
-    __syncthreads();
+    // i-forces: every lane holds 24 partial sums (8 i-clusters x xyz) that have to be added over the 8 lanes sharing
+    // an i-atom.  They go through LDS transposed, half of the i-clusters at a time (the j-force parking area is free
+    // by now and holds exactly 96 x 8 floats): a lane writes its value of (component c, atom a) to word
+    // ((3 a + c) * 8 + tidxj) -- bank (24 tidxi + tidxj) mod 64, conflict-free -- and then sums the eight contiguous
+    // words of one or two outputs.  24 LDS writes, 8 wide reads and 28 adds per entry where the reduce-scatter over
+    // lane shuffles took 21 round trips through the LDS crossbar with a wait each, and 63 selects.
+    float s1 = 0, s2 = 0;   // per lane: sums of the outputs it owned
     {
         float *fi = a.f + (size_t)sci * 192;
-        atomicAdd(&fi[lane], s_red[lane]);
-        atomicAdd(&fi[lane + 64], s_red[lane + 64]);
-        atomicAdd(&fi[lane + 128], s_red[lane + 128]);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int at = k * 8 + tidxi;
+                s_fj[(at * 3) * 8 + tidxj]     = fix[4 * h + k];
+                s_fj[(at * 3 + 1) * 8 + tidxj] = fiy[4 * h + k];
+                s_fj[(at * 3 + 2) * 8 + tidxj] = fiz[4 * h + k];
+            }
+            __syncthreads();
+            {
+                const float4 p0 = *reinterpret_cast<const float4 *>(&s_fj[lane * 8]);
+                const float4 p1 = *reinterpret_cast<const float4 *>(&s_fj[lane * 8 + 4]);
+                const float  o1 = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
+                atomicAdd(&fi[h * 96 + lane], o1);
+                s1 += o1;
+            }
+            if (lane < 32)
+            {
+                const float4 p0 = *reinterpret_cast<const float4 *>(&s_fj[(64 + lane) * 8]);
+                const float4 p1 = *reinterpret_cast<const float4 *>(&s_fj[(64 + lane) * 8 + 4]);
+                const float  o2 = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
+                atomicAdd(&fi[h * 96 + 64 + lane], o2);
+                s2 += o2;
+            }
+            __syncthreads();
+        }
     }
 
 #ifdef NBX_TIMELINE
@@ -723,9 +728,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 #endif
     if (ENER)
     {
-        const float sx = central ? 0.0f : wave_sum(rx);
-        const float sy = central ? 0.0f : wave_sum(ry);
-        const float sz = central ? 0.0f : wave_sum(rz);
+        // s1 holds component lane % 3, s2 (lanes 0-31) component (lane + 1) % 3
+        const int   c1 = lane % 3, c2 = (lane + 1) % 3;
+        const float sx = central ? 0.0f : wave_sum((c1 == 0 ? s1 : 0.0f) + (c2 == 0 ? s2 : 0.0f));
+        const float sy = central ? 0.0f : wave_sum((c1 == 1 ? s1 : 0.0f) + (c2 == 1 ? s2 : 0.0f));
+        const float sz = central ? 0.0f : wave_sum((c1 == 2 ? s1 : 0.0f) + (c2 == 2 ? s2 : 0.0f));
         if (VMOD == 0 && !VDWC)
         {
             // the potential-shift terms, from the sums over the pairs they go with (nbx_eacc_t)
