@@ -7,8 +7,12 @@
 N = 1: BASELINE.json configs[2], the configuration the metric is quoted on: SPC/E water,
 97,200 atoms (spc216 tiled 5x5x6), analytical Ewald real space + LJ, rc = rlist = 1.0 nm,
 energies + virial every step.  (--workload rf gives configs[1]: SPC, reaction field.)
-N > 1: weak scaling: N slabs of that box stacked along z (97,200 x N atoms), one rank per
+N > 1: weak scaling by default: N slabs of that box stacked along z (97,200 x N atoms), one rank per
 GPU, 1-D spatial domain decomposition with RCCL halo exchange (gromacs-cosmo_amd/dd.py).
+--strong: the box given by --tiles is ONE workload cut into N z slabs (BASELINE.json configs[3]:
+`--tiles 13,13,14 --strong` is the 1,533,168-atom box on 1 / 2 / 4 / 8 GPUs; "scaling": "strong").
+`python bench.py --gpus N` starts its own N ranks (child processes, before this process touches the
+GPU) when it is not already running under torch.distributed.run.
 
 One step = clear outputs (folded into the previous kernel launch: ping-pong output buffers,
 nbnxn_hip_set_clear_in_kernel) + nonbonded kernel on coordinates and pair list
@@ -165,6 +169,37 @@ def cpu_baseline(prep, ip, seconds=12.0):
             "sample": f"1 force-only call of the scalar float port over the GPU list, {dt:.1f} s", "ms_per_step": 1e3 * dt}
 
 
+def self_launch(nranks, timeout_s=1500):
+    """`python bench.py --gpus N` as typed: one child per rank with the environment torch.distributed.run would give
+    it (rendezvous on 127.0.0.1, a free port), every child's stderr passed through, rank 0's stdout returned as ours."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    try:
+        out, _ = procs[0].communicate(timeout=timeout_s)
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        for p in procs:
+            rc = max(rc, abs(p.wait(timeout=120)))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:                      # exactly the children started here
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +219,15 @@ def main():
     ap.add_argument("--mcb", type=int, default=-1, help="list split target (-1: nbnxn_hip_min_ci_balanced)")
     ap.add_argument("--precondition", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up steps, so that the timed region runs at the clock the GPU sustains")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --tiles is the whole box, cut into --gpus slabs (default: --tiles per GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: be one.  N fresh child processes, started before this process has imported torch or
+        # touched HIP (a process that holds the GPU must never be replaced or forked into ranks); rank 0's JSON line
+        # is this command's output.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -256,7 +299,7 @@ def main():
         # (nbnxn_hip_dd_*); BENCH_DD_TORCH=1 (and the one-GPU rehearsal, where RCCL cannot run two ranks on one
         # device) sends them through torch.distributed instead
         rccl_direct = not rehearsal and os.environ.get("BENCH_DD_TORCH") != "1"
-        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct)
+        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong)
         rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
@@ -341,11 +384,11 @@ def main():
             "value": value, "unit": "pair/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, numbers meaningless)" if rehearsal else ""),
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, numbers meaningless)" if rehearsal else ""),
             "ns_per_day": 86400.0 * DT_FS * 1e-6 / (ms_per_step * 1e-3),
             "ns_per_day_note": f"nonbonded only, dt = {DT_FS} fs",
             "config": dict({"workload": f"{model.upper()} water {natoms} atoms ({'x'.join(map(str, tiles))} spc216 tiles"
-                                        f"{' per GPU' if world > 1 else ''}), "
+                                        f"{' per GPU' if world > 1 and not args.strong else ''}{', one box cut into ' + str(world) + ' z slabs' if world > 1 and args.strong else ''}), "
                                         f"{'analytical Ewald real-space' if args.workload == 'ewald' else 'reaction-field'} + LJ, "
                                         f"rc=rlist=1.0 nm, {'energies+virial every step' if ener else 'forces only'}",
                             "parallelism": parallelism, "pair_slots_per_step": pair_slots,
@@ -357,7 +400,11 @@ def main():
                          "kernel_ms": kernel_ms, "kernel_ms_events_raw": kernel_ms_raw, "event_pair_ms": event_pair_ms,
                          "note": "algorithmic flops = pair slots x nrnb.c cost (gmxlib/nrnb.c:101-106); duration = mean HIP-event time around the nonbonded kernel launch inside the timed region minus the latency of an empty event pair"},
         }
-        if not args.no_cpu and not decomposed:
+        if not args.no_cpu and not decomposed and natoms > 400000:
+            # a box of BASELINE configs[3] size: the CPU leg alone (bounded); the full-list oracle pass and the
+            # secondary figures belong to the default workload
+            out["cpu_baseline"] = cpu_baseline(prep, ip)
+        elif not args.no_cpu and not decomposed:
             cb = cpu_baseline(prep, ip)
             out["cpu_baseline"] = cb
             chk = oracle_check(prep, ip, f0, e0)

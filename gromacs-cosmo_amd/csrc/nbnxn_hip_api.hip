@@ -141,6 +141,10 @@ struct nbnxn_hip {
     hipStream_t stream[2] = {nullptr, nullptr};
     hipEvent_t  misc_ops_done = nullptr, nonlocal_done = nullptr;
     hipEvent_t  stream_mark[2] = {nullptr, nullptr};   // nbnxn_hip_stream_wait
+    // home coordinates written on the local stream (H2D of xq, x gather) and not yet seen by the non-local stream:
+    // the halo pack of nbnxn_hip_dd_move_x / nbnxn_hip_halo_pack_x reads them there
+    hipEvent_t  x_written = nullptr;
+    bool        x_written_pending = false;
     hipEvent_t  k_start[2] = {nullptr, nullptr}, k_stop[2] = {nullptr, nullptr};
     hipEvent_t  h2d_start[2] = {nullptr, nullptr}, h2d_stop[2] = {nullptr, nullptr};
     hipEvent_t  d2h_start[2] = {nullptr, nullptr}, d2h_stop[2] = {nullptr, nullptr};
@@ -228,6 +232,28 @@ int check_loc(int loc)
     if (loc != NBX_LOCAL && loc != NBX_NONLOCAL)
     {
         return nbx_fail("Invalid locality passed (%d); valid here is only local (%d) or nonlocal (%d)", loc, NBX_LOCAL, NBX_NONLOCAL);
+    }
+    return 0;
+}
+
+// Home coordinates were just written on the local stream: remember it, so that the halo pack on the non-local
+// stream waits for exactly that write (and not for the local kernel behind it, which it is meant to run beside).
+int mark_x_written(nbnxn_hip *nb, int iloc)
+{
+    if (nb->two_streams && iloc == NBX_LOCAL)
+    {
+        HIP_TRY(hipEventRecord(nb->x_written, nb->stream[NBX_LOCAL]));
+        nb->x_written_pending = true;
+    }
+    return 0;
+}
+
+int wait_x_written(nbnxn_hip *nb, hipStream_t st)
+{
+    if (nb->two_streams && nb->x_written_pending && st != nb->stream[NBX_LOCAL])
+    {
+        HIP_TRY(hipStreamWaitEvent(st, nb->x_written, 0));
+        nb->x_written_pending = false;
     }
     return 0;
 }
@@ -556,6 +582,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
             HIP_TRY(hipMemcpyAsync(nb->xq.p + begin, h_xq + (size_t)begin * 4, (size_t)len * sizeof(float4), hipMemcpyHostToDevice, st));
         }
         if (nb->do_time) { HIP_TRY(hipEventRecord(nb->h2d_stop[iloc], st)); nb->h2d_timed[iloc] = true; }
+        if (mark_x_written(nb, iloc)) { return 1; }
     }
 
     nbx_kernel_args_t a;
@@ -763,6 +790,7 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
         HIP_TRY(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&nb->stream_mark[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&nb->stream_mark[1], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&nb->x_written, hipEventDisableTiming));
     }
     else
     {
@@ -1012,6 +1040,7 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     {
         (void)hipEventDestroy(nb->misc_ops_done); (void)hipEventDestroy(nb->nonlocal_done);
         (void)hipEventDestroy(nb->stream_mark[0]); (void)hipEventDestroy(nb->stream_mark[1]);
+        (void)hipEventDestroy(nb->x_written);
         (void)hipStreamDestroy(nb->stream[1]);
     }
     (void)hipStreamDestroy(nb->stream[0]);
@@ -1510,7 +1539,7 @@ int nbnxn_hip_upload_xq_flat(nbnxn_hip_ptr_t nb, const float *xq, int iloc)
     {
         HIP_TRY(hipMemcpyAsync(nb->xq.p + begin, xq + (size_t)begin * 4, (size_t)len * sizeof(float4), hipMemcpyHostToDevice, nb->stream[iloc]));
     }
-    return 0;
+    return mark_x_written(nb, iloc);
 }
 
 int nbnxn_hip_copy_x_to_xq(nbnxn_hip_ptr_t nb, const float *x, int x_on_device, int iloc)
@@ -1535,7 +1564,7 @@ int nbnxn_hip_copy_x_to_xq(nbnxn_hip_ptr_t nb, const float *x, int x_on_device, 
         dx = nb->d_x.p;
     }
     HIP_TRY(nbx_launch_gather_x(nb->d_a.p, dx, nb->xq.p, begin, len, st));
-    return 0;
+    return mark_x_written(nb, iloc);
 }
 
 int nbnxn_hip_add_f(nbnxn_hip_ptr_t nb, float *f, int f_on_device, int a0, int n, int aloc)
@@ -1579,6 +1608,7 @@ int nbnxn_hip_halo_pack_x(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const f
     if (check_halo(nb, d_slots, n, d_buf, iloc)) { return 1; }
     const float zero[3] = {0, 0, 0};
     HIP_TRY(hipSetDevice(nb->device));
+    if (wait_x_written(nb, nb->stream[nb->two_streams ? iloc : 0])) { return 1; }
     HIP_TRY(nbx_launch_halo_pack_x(d_slots, n, nb->xq.p, shift ? shift : zero, reinterpret_cast<float4 *>(d_buf), nb->stream[nb->two_streams ? iloc : 0]));
     return 0;
 }
@@ -1823,6 +1853,8 @@ int nbnxn_hip_dd_move_x(nbnxn_hip_ptr_t nb)
     if (!nb->dd_have_pulse) { return nbx_fail("dd_move_x before dd_set_pulse"); }
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
+    // the home coordinates the pack kernel reads may still be on their way on the local stream (x gather, H2D)
+    if (wait_x_written(nb, st)) { return 1; }
     HIP_TRY(nbx_launch_halo_pack_x(nb->dd_send_slots.p, nb->dd_n_send, nb->xq.p, nb->dd_shift, reinterpret_cast<float4 *>(nb->dd_x_out.p), st));
     RCCL_TRY(g_rccl.GroupStart());
     if (nb->dd_n_send > 0) { RCCL_TRY(g_rccl.Send(nb->dd_x_out.p, (size_t)nb->dd_n_send * 4, ncclFloat, nb->dd_send_to, nb->dd_comm, st)); }

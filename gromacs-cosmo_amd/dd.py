@@ -356,17 +356,19 @@ class _DevArray:
 
 
 class SlabRun:
-    """Weak-scaling workload of bench.py: water_box(tx, ty, tz * world) cut into `world` z slabs."""
+    """The multi-GPU workload of bench.py: water_box(tx, ty, tz * world) (weak scaling) or water_box(tx, ty, tz)
+    (strong scaling, BASELINE configs[3]) cut into `world` z slabs of equal thickness."""
 
     def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None, device_search=True,
-                 device_halo=True, rccl_direct=False):
+                 device_halo=True, rccl_direct=False, strong=False):
         """device_halo: halo buffers packed by the module's kernels (else torch indexing operations), messages
         through torch.distributed.  rccl_direct: everything, messages included, issued by the module on its own
         RCCL communicator (needs one GPU per rank)."""
         from . import gpu
         self.flags = flags
         self.dev = torch.device("cuda", local_rank)
-        glob = sysmod.water_box(tiles[0], tiles[1], tiles[2] * world, model=model)
+        # weak scaling: `tiles` per rank, stacked along z; strong scaling: `tiles` is the whole box, cut into `world` slabs
+        glob = sysmod.water_box(tiles[0], tiles[1], tiles[2] * (1 if strong else world), model=model)
         self.natoms_global = glob.natoms
         self.nb = nb = gpu.NbnxnHip(local_rank, local_and_nonlocal=True)
         mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced

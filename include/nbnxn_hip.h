@@ -611,7 +611,14 @@ int nbnxn_hip_dd_init(nbnxn_hip_ptr_t nb, const char *id128, int rank, int nrank
  * force shift_index as well (-1: not).  Host arrays; copied. */
 int nbnxn_hip_dd_set_pulse(nbnxn_hip_ptr_t nb, int send_to, int recv_from, const int *send_slots, int n_send,
                            const int *recv_slots, int n_recv, const float *shift, int shift_index);
-/* dd_move_x / dd_move_f for that pulse, asynchronous on the non-local stream; every rank calls them */
+/* dd_move_x / dd_move_f for that pulse, asynchronous on the non-local stream; every rank calls them.
+ * Ordering: the pack kernel of dd_move_x (and nbnxn_hip_halo_pack_x) waits for the last write of home coordinates
+ * that this library issued on the LOCAL stream (the H2D of nbnxn_hip_launch_kernel / nbnxn_hip_upload_xq_flat, the
+ * gather of nbnxn_hip_copy_x_to_xq) -- for that write, not for a local kernel launched behind it, beside which the
+ * exchange is meant to run.  A caller that writes the coordinate array by other means (its own kernels through
+ * nbnxn_hip_get_device_buffers) orders that itself (nbnxn_hip_stream_wait).  The next step's coordinate write must
+ * in turn come after this step's pack: nbnxn_hip_stream_wait(nb, NBX_LOCAL, NBX_NONLOCAL) at the end of the step,
+ * which the force reduction needs anyway, gives that. */
 int nbnxn_hip_dd_move_x(nbnxn_hip_ptr_t nb);
 int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb);
 /* in-place ncclAllReduce(sum) of the output slots in use, on the stream of iloc (order it after both

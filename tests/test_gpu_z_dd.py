@@ -41,7 +41,7 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
     dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
                             timeout=datetime.timedelta(seconds=60), **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
     try:
-        ip = g.system.reaction_field(0.9) if model == "spc" else g.system.ewald(0.9)
+        ip = g.system.reaction_field(0.9, rlist=1.0) if model == "spc" else g.system.ewald(0.9, rlist=1.0)
         tiles = (2, 2, 2)
         run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
                          rccl_direct=rccl_direct)
@@ -68,7 +68,27 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
         vir_dd = -0.5 * (xf_t.numpy() + dom.shift_vec.astype(np.float64).T @ e[2:2 + 135].reshape(45, 3))
         vir_ref = virial_from(np.concatenate([glob.x, np.zeros((glob.natoms, 1), np.float32)], 1), f_ref,
                               prep.shift_vec, np.asarray(o["fshift"]))
-        ret[rank] = dict(err=float(np.sqrt(((f_home - fr) ** 2).sum() / (fr ** 2).sum())),
+        # Atoms move between steps: new home coordinates are gathered on the LOCAL stream (nbnxn_hip_copy_x_to_xq) and the
+        # step follows at once; the halo pack on the non-local stream has to wait for that gather.  Forces against the
+        # oracle on the moved coordinates (the lists were built with a buffer: rlist = rc + 0.1 nm).
+        err_moved = 0.0
+        if run.rccl_direct or run.device_halo:
+            rng = np.random.default_rng(99)
+            for it in range(3):
+                x_new = (glob.x + rng.normal(0, 0.004, glob.x.shape)).astype(np.float32)
+                x_all = np.ascontiguousarray(np.concatenate([x_new[dom.home_ids], x_new[dom.halo_ids]]))
+                run.nb.copy_x_to_xq(x_all, abi.LOCAL)
+                run.step()
+            f_moved = run.forces_home()
+            pm = g.workload.prepare(glob, ip, 0)
+            xq_m = pm.xq.copy()
+            pm.host.copy_x_to_xq(x_new, xq_m)
+            om = O.kernel_gpu_list(xq_m, pm.type, pm.ntype, pm.nbfp, pm.shift_vec, pm.pl, ip)
+            f_ref_m = np.zeros((glob.natoms, 3), dtype=np.float32)
+            pm.host.add_f(np.asarray(om["f"], dtype=np.float32), f_ref_m)
+            frm = f_ref_m[dom.home_ids]
+            err_moved = float(np.sqrt(((f_moved - frm) ** 2).sum() / (frm ** 2).sum()))
+        ret[rank] = dict(err=float(np.sqrt(((f_home - fr) ** 2).sum() / (fr ** 2).sum())), err_moved=err_moved,
                          e_lj=float(e[0]), e_el=float(e[1]), e_lj_ref=float(o["Vvdw"]), e_el_ref=float(o["Vc"]),
                          vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()))
     finally:
@@ -98,24 +118,31 @@ def test_slabrun_two_ranks_one_gpu(model, device_halo):
         _watch(ctx)
         res = [ret[r] for r in range(2)]
     for r in res:
-        assert r["err"] < 1e-5, r
+        assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
         assert r["vir_err"] < 1e-5, r
 
 
+@pytest.mark.parametrize("reserve_cus", ["default", "0"])
 @pytest.mark.parametrize("model,rccl_direct", [("spce", True), ("spc", True), ("spce", False)])
-def test_slabrun_one_rank_over_rccl(model, rccl_direct):
+def test_slabrun_one_rank_over_rccl(model, rccl_direct, reserve_cus, monkeypatch):
     """The whole decomposed step over the RCCL backend on the one GPU of the box: ONE rank that is its own neighbour
     (periodic in z through a halo of its own atoms), so every message is a real RCCL send / receive (to itself) and the
     reduction a real all-reduce.  rccl_direct: issued by the HIP module (nbnxn_hip_dd_*, what bench.py --gpus N uses);
     otherwise through torch.distributed (all_to_all_single).  Forces, energies and virial against the single-domain
     oracle."""
+    # both kinds of local stream: with the CU reservation (a CU-masked stream, the coordinate exchange issued beside the
+    # local kernel) and without it (an ordinary non-blocking stream, the exchange issued first)
+    if reserve_cus == "0":
+        monkeypatch.setenv("GMX_HIP_NB_RESERVE_CUS", "0")
+    else:
+        monkeypatch.delenv("GMX_HIP_NB_RESERVE_CUS", raising=False)
     with mp.Manager() as m:
         ret = m.dict()
         _watch(mp.spawn(_worker, args=(1, _free_port(), model, True, ret, "nccl", rccl_direct), nprocs=1, join=False))
         r = ret[0]
-    assert r["err"] < 1e-5, r
+    assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
     assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
     assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
     assert r["vir_err"] < 1e-5, r
@@ -253,3 +280,30 @@ def test_module_rccl_path_single_rank():
         ret = m.dict()
         _watch(mp.spawn(_rccl_direct_worker, args=(_free_port(), ret), nprocs=1, join=False))
         assert ret["ok"] and ret["refused"] == 4
+
+
+def test_bench_starts_its_own_ranks_and_cuts_one_box():
+    """`python bench.py --gpus 2 ... --strong` as the driver types it (no launcher): the script starts its two ranks
+    itself, before it touches the GPU, and cuts ONE box into two slabs (BASELINE configs[3] in small).  On this
+    one-GPU box both ranks share cuda:0 over gloo (BENCH_REHEARSAL=1): the plumbing is what is checked, not a number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--tiles", "2,2,4", "--strong", "--steps", "3",
+                        "--warmup", "1", "--precondition", "0"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert "10368 atoms" in d["config"]["workload"] and "cut into 2 z slabs" in d["config"]["workload"]
+    # the same box on one rank, no launcher either: the two ranks together hold the same list
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--tiles", "2,2,4", "--strong", "--steps", "3",
+                         "--warmup", "1", "--precondition", "0", "--no-cpu"], env=env, capture_output=True, text=True, timeout=280)
+    assert r1.returncode == 0, r1.stderr[-800:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and "10368 atoms" in d1["config"]["workload"]
+    assert abs(d["config"]["pair_slots_per_step"] - d1["config"]["pair_slots_per_step"]) < 0.02 * d1["config"]["pair_slots_per_step"]
