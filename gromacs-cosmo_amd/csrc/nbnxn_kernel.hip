@@ -241,18 +241,21 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
     // 0 for an excluded pair, all ones otherwise
     int         m;
-    float       r2e;
-    // (both as asm: left to itself the compiler turns the pair into v_and + v_cmp + two v_cndmask + a v_mov)
+    // (as asm: left to itself the compiler turns it into v_and + v_cmp + v_cndmask)
     __asm__("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(wexcl), "n"(bitpos));
-    __asm__("v_bfi_b32 %0, %1, 0, %2" : "=v"(r2e) : "v"(m), "s"(r2inc));     // ~m & r2inc
     // the reference's r^2 += (1 - int_bit) * NBNXN_AVOID_SING_R2_INC (nbnxn_consts.h:66-79,
     // nbnxn_cuda_kernel.cuh:371, nbnxn_kernel_ref_inner.h:132): two distinct, mutually excluded atoms may sit on
-    // one point (shells, virtual sites); their Ewald / reaction-field / LJ-PME correction must stay finite.  The
-    // increment (in the kernel's scaled units) rides in the first fma of the distance, so it costs the one mask
-    // instruction; it is far below an ulp of rc^2 / rlist^2, so cut-off and pruning decisions are the reference's.
-    const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, r2e)));
+    // one point (shells, virtual sites); their Ewald / reaction-field / LJ-PME correction must stay finite.  Here the
+    // increment (in the kernel's scaled units, from a VGPR) starts the fma chain of EVERY pair: for a pair that
+    // interacts it is below half an ulp of r^2 from r = 0.005 nm on (1e-12 / r^2 < 2^-25), far inside any LJ core, so
+    // those pairs get the same float r^2 as without it and the mask instruction of the selective form is saved; it is
+    // also far below an ulp of rc^2 / rlist^2, so cut-off and pruning decisions are the reference's.
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, r2inc)));
     if (PRUNE) { any_in_rlist = __any(r2 < a.k.rlist2); }
-    const bool  cond = (r2 < a.k.rc2) && allowed;
+    // The cut-off and the j > i rule of a diagonal cluster pair go into the EXEC mask: lanes outside take no part in
+    // what follows, so nothing below selects on the cut-off or multiplies by a 0 / 1 factor, and values that would
+    // overflow there (filler atoms sit thousands of nm away) are never computed.
+    if (!((r2 < a.k.rc2) && allowed)) { return; }
     const float inv_r  = __builtin_amdgcn_rsqf(r2);
     if (VMOD == 0 && !VDWC && ENER)
     {
@@ -275,10 +278,8 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
         }
         else
         {
-            // the cut-off acts as a FACTOR below, so what it discards must be finite: filler atoms sit thousands of nm
-            // away, where the fits' polynomials overflow.  The fits hold on [0, 16]; beyond rc the value is not used
             float gf, gv;
-            pme_corr_fv(fminf(r2, 16.0f), gf, gv);
+            pme_corr_fv(r2, gf, gv);
             if (EL == NBX_EL_EWALD_TAB)
             {
                 const float rs  = fminf(r2 * inv_r * a.k.tab_scale, a.k.tab_max);
@@ -290,13 +291,11 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
             else { F = fmaf(qq, gf, t); }
             ec = inv_rm - gv;
         }
-        const float wc = cond ? 1.0f : 0.0f;
-        const float ws = and_mask(wc, m);
-        F *= wc;
-        acc.lj  = fmaf(fmaf(-c.x, u6, lj6), wc, acc.lj);             // 12 x [c12 r^-12 / 12 - c6 r^-6 / 6]
+        const float ws = and_mask(1.0f, m);
+        acc.lj  += fmaf(-c.x, u6, lj6);                               // 12 x [c12 r^-12 / 12 - c6 r^-6 / 6]
         acc.s12 = fmaf(c.y, ws, acc.s12);
         acc.s6  = fmaf(c.x, ws, acc.s6);
-        acc.el  = fmaf(qq * wc, ec, acc.el);
+        acc.el  = fmaf(qq, ec, acc.el);
         if (EL != NBX_EL_RF) { acc.sq = fmaf(qq, ws, acc.sq); }
         fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
         fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
@@ -403,14 +402,13 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
         else { gf = pme_corr_f(r2); }
         F = fmaf(qq, gf, t);
     }
-    F = cond ? F : 0.0f;
     if (ENER)
     {
         float eel;
         if (EL == NBX_EL_RF) { eel = qq * (and_mask(inv_r, m) + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf)); }
         else { eel = qq * (and_mask(inv_r - a.k.sh, m) - gv); }
-        acc.lj += cond ? elj : 0.0f;
-        acc.el += cond ? eel : 0.0f;
+        acc.lj += elj;
+        acc.el += eel;
     }
     fjx = fmaf(-dx, F, fjx); fjy = fmaf(-dy, F, fjy); fjz = fmaf(-dz, F, fjz);
     fix = fmaf(dx, F, fix);  fiy = fmaf(dy, F, fiy);  fiz = fmaf(dz, F, fiz);
@@ -458,7 +456,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
                                             unsigned &imask, const bool central, const int sci, const int tidxi,
                                             const int tidxj, const int lane, const float2 *s_nbfp, float *s_fj,
                                             int *s_fjc, int &nfj, nbx_eacc_t &acc, const float ox, const float oy,
-                                            const float oz)
+                                            const float oz, const float r2inc)
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
     float2 c[8];
@@ -509,7 +507,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, a.k.r2inc,
+            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, r2inc,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, acc, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
@@ -619,6 +617,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
     }
 
+    // the r^2 increment lives in a VGPR: as the addend of the distance's first fma it would otherwise be an SGPR
+    // operand, and a VALU instruction with one issues at half rate (tools/ubench/valu_mix.hip)
+    float r2inc_v;
+    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(r2inc_v) : "s"(a.k.r2inc));
+
     nbx_eacc_t acc;
     if (ENER)
     {
@@ -642,7 +645,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 #define NBX_JCLUSTER(JM, SLOT)                                                                             \
     jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
-                                               nfj, acc, ox, oy, oz)
+                                               nfj, acc, ox, oy, oz, r2inc_v)
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
     {
         // software pipeline: the next group's list words are requested before this group's
