@@ -28,6 +28,15 @@ extern "C" int nbnxn_hip_debug_timeline(unsigned long long *out, int n)
 }
 #endif
 
+// raw buffer loads (the builtin of this compiler release loads a single dword whatever its width; the intrinsic
+// declared by its LLVM name does what it says)
+typedef int   nbx_i32x4 __attribute__((ext_vector_type(4)));
+typedef float nbx_f32x4 __attribute__((ext_vector_type(4)));
+__device__ nbx_f32x4 nbx_buffer_load_f32x4(nbx_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ int       nbx_buffer_load_i32(nbx_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+// v_writelane_b32: lane `lane` of the result is val, the others keep old
+__device__ int       nbx_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
 namespace {
 
 
@@ -164,15 +173,6 @@ __device__ __forceinline__ float reduce8(float v)
     return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v = reduce8(v);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-
 constexpr int MAX_LDS_TYPES = NBX_KERNEL_MAX_LDS_TYPES;
 
 // A third per-type-pair value rides with {c6, c12} for LJ-PME: the grid C6.
@@ -186,26 +186,6 @@ constexpr int lds_entry_bytes(int vmod, bool ener) { return has_third(vmod, ener
 struct nbx_eacc_t {
     float lj = 0, el = 0, s12 = 0, s6 = 0, sq = 0;
 };
-
-// j-forces are not sent to memory one cluster at a time: on CDNA the wave's loads, stores
-// and atomics retire in order through one counter (vmcnt), so a load issued after an atomic
-// cannot be waited for without also waiting for that atomic's round trip to the memory side
-// (~1-3 us under load).  The reduced j-forces of up to FJ_CAP clusters are parked in LDS and
-// flushed as full 64-lane atomic instructions; the kernel's loads then only wait for loads.
-template <int FJ_CAP>
-__device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int *s_fjc, int n, int lane)
-{
-    __syncthreads();
-    for (int idx = lane; idx < n * 24; idx += 64)
-    {
-        const int cl   = (idx * 2731) >> 16;   // idx / 24 for idx < 4096
-        const int comp = idx - cl * 24;
-        atomicAdd(&f[s_fjc[cl] * 24 + comp], s_fj[idx]);
-    }
-    __syncthreads();
-}
-
-
 
 // ---------------------------------------------------------------------------------------
 // The kernel.  Its shape came out of reading the gfx950 code of two earlier variants (kept in
@@ -425,37 +405,73 @@ struct nbx_jslot_t {
     int    t;
 };
 
+// buffer resources of the coordinate and type arrays plus this lane's byte offsets into a cluster's rows
+struct nbx_jsrc_t {
+    nbx_i32x4 rx, rt;
+    int       voff16, voff4;
+};
+
+__device__ __forceinline__ nbx_i32x4 make_rsrc(const void *p)
+{
+    // raw buffer (stride 0), no range limit: the offsets come from the list, which the API checks against natoms
+    const unsigned long long a = (unsigned long long)p;
+    nbx_i32x4                r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    r.z = -1;
+    r.w = 0x00020000;
+    return r;
+}
+
 __device__ __forceinline__ void load_jhdr(const nbx_kernel_view_t &a, int j4, int lane, nbx_jhdr_t &h)
 {
-    const nbx_cj4_t *g = a.cj4 + j4;
-    h.imask = g->imei[0].imask | g->imei[1].imask;
-    const int ei0 = g->imei[0].excl_ind, ei1 = g->imei[1].excl_ind;
+    // the whole 32-byte group in one scalar load; slots without interaction bits hold undefined j-clusters
+    // (nbnxn_search.c:2460-2472): cluster 0 is read for them instead
+    const int4 *g  = reinterpret_cast<const int4 *>(a.cj4 + j4);
+    const int4  w0 = g[0];   // cj[4]
+    const int4  w1 = g[1];   // imei[0].imask, imei[0].excl_ind, imei[1].imask, imei[1].excl_ind
+    h.imask = (unsigned)w1.x | (unsigned)w1.z;
+    const int ei0 = w1.y, ei1 = w1.w;
     // excl[0] is the shared all-ones entry (types/nbnxn_pairlist.h:197-199): no load for it
     h.wexcl = 0xffffffffu;
     if ((ei0 | ei1) != 0) { h.wexcl = a.excl[lane < 32 ? ei0 : ei1].pair[lane & 31]; }
-#pragma unroll
-    for (int jm = 0; jm < 4; jm++)
-    {
-        // slots without interaction bits hold undefined j-clusters: read cluster 0 instead
-        h.cj[jm] = (h.imask >> (8 * jm)) & 0xffu ? g->cj[jm] : 0;
-    }
+    h.cj[0] = (h.imask & 0x000000ffu) ? w0.x : 0;
+    h.cj[1] = (h.imask & 0x0000ff00u) ? w0.y : 0;
+    h.cj[2] = (h.imask & 0x00ff0000u) ? w0.z : 0;
+    h.cj[3] = (h.imask & 0xff000000u) ? w0.w : 0;
 }
 
-__device__ __forceinline__ void load_jslot(const nbx_kernel_view_t &a, int cj, int tidxj, nbx_jslot_t &s)
+__device__ __forceinline__ void load_jslot(const nbx_jsrc_t &js, int cj, nbx_jslot_t &s)
 {
-    // unsigned index: base pointer in SGPRs + zero-extended 32-bit lane offset, no 64-bit address arithmetic per lane
-    const unsigned idx = (unsigned)(cj * 8 + tidxj);
-    s.x = a.xq[idx];
-    s.t = a.type[idx];
+    // buffer loads: the wave-uniform cluster offset rides in an SGPR, the lane's row offset is a constant VGPR --
+    // no address arithmetic per j-cluster
+    const nbx_f32x4 v = nbx_buffer_load_f32x4(js.rx, js.voff16, cj * 128, 0);
+    s.x = make_float4(v.x, v.y, v.z, v.w);
+    s.t = nbx_buffer_load_i32(js.rt, js.voff4, cj * 32, 0);
 }
+
+// Per-entry LJ table in LDS (NBFP_LDS): for every j-type a row of [tidxi][i-cluster] parameter entries of THIS entry's
+// 64 i-atoms, so a lane finds the eight entries it needs for a j-atom of type tj at consecutive addresses
+// tj * row + tidxi * 8 * E + i * E: one multiply-add for the address and four (E = 8) or eight (E = 16) 16-byte reads
+// with immediate offsets per j-cluster, where a shared [tj][ti] table costs an address per pair.  Rows are padded by
+// Bank layout: a 16-byte read is served in groups of 16 lanes that hold positions 0-3 of two j-atoms and positions
+// 4-7 of two others (MI355X_MICROARCH.md, LDS), each lane taking 4 of the 64 banks.  With 8-byte entries a position's
+// eight entries are 64 bytes; positions 4-7 are shifted by 16 bytes and rows by 32 bytes (mod 256), so that the four
+// positions of a half and the rows of two j-types tile the banks exactly.  With 16-byte entries positions are 144 bytes
+// apart (9 bank quads: the eight positions fall into eight different quads).
+constexpr int ljt_pos_bytes(int vmod, bool ener, int pos)
+{
+    return lds_entry_bytes(vmod, ener) == 8 ? pos * 64 + (pos >> 2) * 16 : pos * 144;
+}
+constexpr int ljt_row_bytes(int vmod, bool ener) { return lds_entry_bytes(vmod, ener) == 8 ? 544 : 1168; }
 
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS, int JM>
 __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
                                             const unsigned thi, float (&fix)[8], float (&fiy)[8], float (&fiz)[8],
                                             const nbx_jslot_t &s, const int cj, const unsigned wexcl,
                                             unsigned &imask, const bool central, const int sci, const int tidxi,
-                                            const int tidxj, const int lane, const float2 *s_nbfp, float *s_fj,
-                                            int *s_fjc, int &nfj, nbx_eacc_t &acc, const float ox, const float oy,
+                                            const int tidxj, const char *ljt_lane, float *s_fj_lane,
+                                            int &cjs, int &nfj, nbx_eacc_t &acc, const float ox, const float oy,
                                             const float oz, const float r2inc)
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
@@ -465,22 +481,26 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     constexpr bool THIRD = has_third(VMOD, ENER);
     if (NBFP_LDS)
     {
-        const char *row = reinterpret_cast<const char *>(s_nbfp) + s.t * (MAX_LDS_TYPES * TS);
-#pragma unroll
-        for (int i = 0; i < 8; i++)
+        const char *row = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
+        if (THIRD)
         {
-            const unsigned tb = ((i < 4 ? tlo : thi) >> (8 * (i & 3))) & 0xffu;
-            if (THIRD)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
             {
-                // 16-byte entries at 16-byte aligned addresses: one ds_read_b128 (the fourth word is padding)
-                const float4 v = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(row + tb, 16));
+                const float4 v = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(row + 16 * i, 16));
                 c[i]  = make_float2(v.x, v.y);
                 cg[i] = v.z;
             }
-            else
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
             {
-                c[i]  = *reinterpret_cast<const float2 *>(row + tb);
-                cg[i] = 0.0f;
+                const float4 v = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(row + 16 * k, 16));
+                c[2 * k]     = make_float2(v.x, v.y);
+                c[2 * k + 1] = make_float2(v.z, v.w);
+                cg[2 * k] = cg[2 * k + 1] = 0.0f;
             }
         }
     }
@@ -517,9 +537,40 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     // can no longer be folded into the add (a DPP source lane must be active)
     __asm__ volatile("" : "+v"(fjx), "+v"(fjy), "+v"(fjz));
     const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
-    if (tidxi < 3) { s_fj[nfj * 24 + tidxj * 3 + tidxi] = fj; }
-    if (lane == 0) { s_fjc[nfj] = cj; }
+    if (tidxi < 3) { s_fj_lane[nfj * 24] = fj; }
+    // the parked cluster's index goes into lane nfj of a register (one v_writelane, no LDS traffic, no exec change)
+    cjs = nbx_writelane(cj, nfj, cjs);
     nfj++;
+}
+
+// j-forces are not sent to memory one cluster at a time: on CDNA the wave's loads, stores
+// and atomics retire in order through one counter (vmcnt), so a load issued after an atomic
+// cannot be waited for without also waiting for that atomic's round trip to the memory side
+// (~1-3 us under load).  The reduced j-forces of up to FJ_CAP clusters are parked in LDS and
+// flushed as full 64-lane atomic instructions; the kernel's loads then only wait for loads.
+__device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int cjs, int n, int lane)
+{
+    __syncthreads();
+    // (the lane read takes place with every lane active: a cross-lane read from a lane that has left the loop returns 0)
+    for (int base = 0; base < n * 24; base += 64)
+    {
+        const int idx  = base + lane;
+        const int cl   = (idx * 2731) >> 16;   // idx / 24 for idx < 4096
+        const int comp = idx - cl * 24;
+        const int cj   = __shfl(cjs, cl);
+        if (idx < n * 24) { atomicAdd(&f[(unsigned)(cj * 24 + comp)], s_fj[idx]); }
+    }
+    __syncthreads();
+}
+
+// sum over the wave with DPP moves only (no LDS round trips); the result is valid in lanes 48..63
+__device__ __forceinline__ float wave_sum_hi(float v)
+{
+    v = reduce8(v);
+    v = dpp_add<0x140>(v);   // row_mirror: every lane of a row holds the row's sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+    return v;
 }
 
 #ifndef NBX_KERNEL_WAVES
@@ -535,14 +586,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     const int tidxj = lane >> 3;
 
     __shared__ float4 s_xqi[64];
-    __shared__ int    s_ti[64];
-    // LJ table transposed and padded to rows of 16: s_nbfp[tj * 16 + ti]
-    constexpr int     TS = lds_entry_bytes(VMOD, ENER);
-    __shared__ __attribute__((aligned(16))) float2 s_nbfp[NBFP_LDS ? MAX_LDS_TYPES * MAX_LDS_TYPES * (TS / 8) : 1];
+    __shared__ int    s_ti[NBFP_LDS ? 1 : 64];
+    constexpr int     TS     = lds_entry_bytes(VMOD, ENER);
+    constexpr int     ROW    = ljt_row_bytes(VMOD, ENER);
     constexpr int     FJ_CAP = 32;
-    __shared__ float  s_fj[FJ_CAP * 24];
-    __shared__ int    s_fjc[FJ_CAP];
+    // j-force parking area; at the start of an entry it holds the staged LJ table (MAX_LDS_TYPES^2 x 12 bytes = 3 KB),
+    // at its end the transposed i-forces
+    __shared__ __attribute__((aligned(16))) float s_fj[FJ_CAP * 24];
+    static_assert(MAX_LDS_TYPES * MAX_LDS_TYPES * 12 <= FJ_CAP * 24 * 4, "staged LJ table must fit the parking area");
+    // per-entry LJ table, ntype rows of ROW bytes (dynamic: sized by the launch)
+    extern __shared__ __attribute__((aligned(16))) char s_ljt[];
     int               nfj = 0;
+    int               cjs = 0;
 
 #ifdef NBX_TIMELINE
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
@@ -556,39 +611,70 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
     // accumulates into it, so no fill has to be dispatched between two steps
     for (int i = blockIdx.x * 64 + lane; i < p_zero_n4; i += gridDim.x * 64) { p_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 
+    nbx_jsrc_t js;
+    js.rx     = make_rsrc(a.xq);
+    js.rt     = make_rsrc(a.type);
+    js.voff16 = tidxj * 16;
+    js.voff4  = tidxj * 4;
+
     nbx_jhdr_t  cur;
     nbx_jslot_t sa, sb;
     cur.imask = 0; cur.wexcl = 0xffffffffu;
     cur.cj[0] = cur.cj[1] = cur.cj[2] = cur.cj[3] = 0;
     if (e.cj4_ind_start < e.cj4_ind_end) { load_jhdr(a, e.cj4_ind_start, lane, cur); }
-    load_jslot(a, cur.cj[0], tidxj, sa);
+    load_jslot(js, cur.cj[0], sa);
 
+    int ti;
     {
-        const int ai = sci * 64 + lane;
-        float4    x  = a.xq[ai];
-        x.x += a.shift_vec[3 * e.shift + 0];
-        x.y += a.shift_vec[3 * e.shift + 1];
-        x.z += a.shift_vec[3 * e.shift + 2];
-        x.w *= a.k.qscale;
+        const nbx_f32x4 v = nbx_buffer_load_f32x4(js.rx, lane * 16, sci * 1024, 0);
+        ti                = nbx_buffer_load_i32(js.rt, lane * 4, sci * 256, 0);
+        float4 x;
+        x.x = v.x + a.shift_vec[3 * e.shift + 0];
+        x.y = v.y + a.shift_vec[3 * e.shift + 1];
+        x.z = v.z + a.shift_vec[3 * e.shift + 2];
+        x.w = v.w * a.k.qscale;
         s_xqi[lane] = x;
-        s_ti[lane]  = a.type[ai];
         if (NBFP_LDS)
         {
+            // the type-pair table as it lies in memory ([ti][tj]), scaled, staged in the parking area
+            float2 *stage  = reinterpret_cast<float2 *>(s_fj);
+            float  *stage3 = s_fj + 2 * MAX_LDS_TYPES * MAX_LDS_TYPES;
             for (int k = lane; k < ntype * ntype; k += 64)
             {
-                const int t_i = k / ntype, t_j = k - t_i * ntype;
-                float2    c   = a.nbfp[k];
+                float2 c = a.nbfp[k];
                 if (EL != NBX_EL_RF) { c.x *= a.k.c6scale; c.y *= a.k.c12scale; }
-                char *entry = reinterpret_cast<char *>(s_nbfp) + (t_j * MAX_LDS_TYPES + t_i) * TS;
-                *reinterpret_cast<float2 *>(entry) = c;
-                if (VMOD == 3) { *reinterpret_cast<float *>(entry + 8) = a.c6grid[k] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
+                stage[k] = c;
+                if (VMOD == 3) { stage3[k] = a.c6grid[k] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
             }
         }
+        else { s_ti[lane] = ti; }
     }
     __syncthreads();
 
+    float c6ii = 0.0f;   // LJ-PME self term
+    if (NBFP_LDS)
+    {
+        // this lane as i-atom (cluster lane / 8, position lane % 8) fills its column of every j-type's row
+        const float2 *stage  = reinterpret_cast<const float2 *>(s_fj);
+        const float  *stage3 = s_fj + 2 * MAX_LDS_TYPES * MAX_LDS_TYPES;
+        char         *dst    = s_ljt + (TS == 8 ? tidxi * 64 + (tidxi >> 2) * 16 : tidxi * 144) + tidxj * TS;
+        const int     base   = ti * ntype;
+#pragma unroll 4
+        for (int tj = 0; tj < ntype; tj++)
+        {
+            const float2 c = stage[base + tj];
+            if (has_third(VMOD, ENER))
+            {
+                *reinterpret_cast<float4 *>(__builtin_assume_aligned(dst + tj * ROW, 16)) = make_float4(c.x, c.y, stage3[base + tj], 0.0f);
+            }
+            else { *reinterpret_cast<float2 *>(dst + tj * ROW) = c; }
+        }
+        if (ENER && VMOD == 3) { c6ii = stage[base + ti].x; }
+    }
+    else if (ENER && VMOD == 3) { c6ii = a.nbfp[ti * ntype + ti].x * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
+
     // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
-    // their types are packed one per byte (LDS path: as byte offsets type*8 into a table row)
+    // (global-table path: their types are packed one per byte)
     // Ewald: the scaled coordinates are x' = fma(x, beta, C) with C = -fl(beta * o), o the entry's first (shifted)
     // i-atom.  The product is exact inside the fma and C is the SAME number for every i- and j-atom of the entry, so
     // it cancels in x_i' - x_j': what is left is the rounding of two numbers of local magnitude (ulp(beta * 3 nm)),
@@ -612,8 +698,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         {
             xi[i].x = fmaf(xi[i].x, a.k.xscale, ox); xi[i].y = fmaf(xi[i].y, a.k.xscale, oy); xi[i].z = fmaf(xi[i].z, a.k.xscale, oz);
         }
-        const unsigned t = (unsigned)s_ti[i * 8 + tidxi] * (NBFP_LDS ? (unsigned)TS : 1u);
-        if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
+        if (!NBFP_LDS)
+        {
+            const unsigned t = (unsigned)s_ti[i * 8 + tidxi];
+            if (i < 4) { tlo |= t << (8 * i); } else { thi |= t << (8 * (i - 4)); }
+        }
         fix[i] = 0; fiy[i] = 0; fiz[i] = 0;
     }
 
@@ -630,21 +719,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
             // self term (nbnxn_cuda_kernel.cuh:239-262) in the scaled charges
             const float q = s_xqi[lane].w;
             acc.el = a.k.self * q * q;
-            if (VMOD == 3)
-            {
-                // LJ-PME self term: 0.5 * C6_ii / 6 * cl^6 / 6 per atom (nbnxn_cuda_kernel.cuh:232-246)
-                const int ti = s_ti[lane];
-                float     c6ii;
-                if (NBFP_LDS) { c6ii = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_nbfp) + (ti * MAX_LDS_TYPES + ti) * TS); }
-                else { c6ii = a.nbfp[ti * ntype + ti].x * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
-                acc.lj = c6ii * (0.5f / 6.0f) * a.k.lje6_6;
-            }
+            // LJ-PME self term: 0.5 * C6_ii / 6 * cl^6 / 6 per atom (nbnxn_cuda_kernel.cuh:232-246)
+            if (VMOD == 3) { acc.lj = c6ii * (0.5f / 6.0f) * a.k.lje6_6; }
         }
     }
+    // the per-entry table is complete and the staged copy no longer needed: the parking area is free
+    __syncthreads();
+
+    const char *ljt_lane  = s_ljt + (TS == 8 ? tidxi * 64 + (tidxi >> 2) * 16 : tidxi * 144);
+    float      *s_fj_lane = s_fj + tidxj * 3 + (tidxi < 3 ? tidxi : 0);
 
 #define NBX_JCLUSTER(JM, SLOT)                                                                             \
     jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
-                                               imask, central, sci, tidxi, tidxj, lane, s_nbfp, s_fj, s_fjc,  \
+                                               imask, central, sci, tidxi, tidxj, ljt_lane, s_fj_lane, cjs,  \
                                                nfj, acc, ox, oy, oz, r2inc_v)
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
     {
@@ -656,13 +743,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
         if (j4 + 1 < e.cj4_ind_end) { load_jhdr(a, j4 + 1, lane, nxt); }
 
         unsigned imask = cur.imask;
-        load_jslot(a, cur.cj[1], tidxj, sb);
+        load_jslot(js, cur.cj[1], sb);
         NBX_JCLUSTER(0, sa);
-        load_jslot(a, cur.cj[2], tidxj, sa);
+        load_jslot(js, cur.cj[2], sa);
         NBX_JCLUSTER(1, sb);
-        load_jslot(a, cur.cj[3], tidxj, sb);
+        load_jslot(js, cur.cj[3], sb);
         NBX_JCLUSTER(2, sa);
-        load_jslot(a, nxt.cj[0], tidxj, sa);
+        load_jslot(js, nxt.cj[0], sa);
         NBX_JCLUSTER(3, sb);
 
         if (PRUNE)
@@ -674,10 +761,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
             }
         }
         cur = nxt;
-        if (nfj > FJ_CAP - 4) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); nfj = 0; }
+        if (nfj > FJ_CAP - 4) { flush_fj(a.f, s_fj, cjs, nfj, lane); nfj = 0; }
     }
 #undef NBX_JCLUSTER
-    if (nfj > 0) { flush_fj<FJ_CAP>(a.f, s_fj, s_fjc, nfj, lane); }
+    if (nfj > 0) { flush_fj(a.f, s_fj, cjs, nfj, lane); }
 
     // i-forces: every lane holds 24 partial sums (8 i-clusters x xyz) that have to be added over the 8 lanes sharing
     // an i-atom.  They go through LDS transposed, half of the i-clusters at a time (the j-force parking area is free
@@ -731,36 +818,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KER
 #endif
     if (ENER)
     {
-        // s1 holds component lane % 3, s2 (lanes 0-31) component (lane + 1) % 3
-        const int   c1 = lane % 3, c2 = (lane + 1) % 3;
-        const float sx = central ? 0.0f : wave_sum((c1 == 0 ? s1 : 0.0f) + (c2 == 0 ? s2 : 0.0f));
-        const float sy = central ? 0.0f : wave_sum((c1 == 1 ? s1 : 0.0f) + (c2 == 1 ? s2 : 0.0f));
-        const float sz = central ? 0.0f : wave_sum((c1 == 2 ? s1 : 0.0f) + (c2 == 2 ? s2 : 0.0f));
         if (VMOD == 0 && !VDWC)
         {
             // the potential-shift terms, from the sums over the pairs they go with (nbx_eacc_t)
             acc.lj = fmaf(12.0f, fmaf(acc.s12, a.k.rep12, acc.s6 * a.k.ndisp6), acc.lj);
             if (EL != NBX_EL_RF) { acc.el = fmaf(-a.k.sh, acc.sq, acc.el); }
         }
-        const float E_lj = wave_sum(acc.lj) * a.k.escale * (VMOD == 0 ? 1.0f / 12.0f : 1.0f);
-        const float E_el = wave_sum(acc.el) * a.k.escale;
-        // lanes 0..4 add {fshift xyz, e_lj, e_el} into this entry's accumulation slot
+        const float E_lj = wave_sum_hi(acc.lj) * a.k.escale * (VMOD == 0 ? 1.0f / 12.0f : 1.0f);
+        const float E_el = wave_sum_hi(acc.el) * a.k.escale;
+        // the sums are complete in the wave's last lanes: lanes 59..61 add the shift force, 62 / 63 the energies
+        // into this entry's accumulation slot
         float *slot = a.out + (size_t)(blockIdx.x & (NBX_OUT_SLOTS - 1)) * NBX_OUT_STRIDE;
-        if (lane < 3)
+        if (!central)
         {
-            if (!central) { atomicAdd(&slot[2 + 3 * e.shift + lane], lane == 0 ? sx : (lane == 1 ? sy : sz)); }
+            // s1 holds component lane % 3, s2 (lanes 0-31) component (lane + 1) % 3
+            const int   c1 = lane % 3, c2 = (lane + 1) % 3;
+            const float sx = wave_sum_hi((c1 == 0 ? s1 : 0.0f) + (c2 == 0 ? s2 : 0.0f));
+            const float sy = wave_sum_hi((c1 == 1 ? s1 : 0.0f) + (c2 == 1 ? s2 : 0.0f));
+            const float sz = wave_sum_hi((c1 == 2 ? s1 : 0.0f) + (c2 == 2 ? s2 : 0.0f));
+            if (lane >= 59 && lane < 62) { atomicAdd(&slot[2 + 3 * e.shift + (lane - 59)], lane == 59 ? sx : (lane == 60 ? sy : sz)); }
         }
-        else if (lane < 5)
-        {
-            atomicAdd(&slot[lane - 3], lane == 3 ? E_lj : E_el);
-        }
+        if (lane >= 62) { atomicAdd(&slot[lane - 62], lane == 62 ? E_lj : E_el); }
     }
 }
 
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
 void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
 {
-    if (a.ntype <= MAX_LDS_TYPES) { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, true>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
+    if (a.ntype <= MAX_LDS_TYPES)
+    {
+        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, true>), dim3(nsci), dim3(64), (size_t)a.ntype * ljt_row_bytes(VMOD, ENER), stream,
+                           NBX_KERNEL_CALL_ARGS(a));
+    }
     else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }
 }
 
