@@ -141,32 +141,66 @@ def verlet_loop_leg(g, abi, system, ip, flags, nstlist=10, nsteps=100):
             "note": "forces only; device search + x gather + kernel + f scatter per step, caller-order x and f resident in HBM"}
 
 
-def cpu_baseline(prep, ip, seconds=12.0):
-    """The reference's plain-C nbnxn_kernel_ref (oracle/_ref, compiled from the reference tree)
-    on the host cores, same atoms and pairs (as a 4x4 list); falls back to the repo's scalar
-    float port when oracle/_ref was not built.  Bounded sample: repeats for ~`seconds`."""
+def cpu_threads():
+    """Threads for the CPU yardstick: the box's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where
+    os.cpu_count() shows the whole machine), at most the cores this process may run on and the reference's own limit of
+    32 lists (NBNXN_BUFFERFLAG_MAX_THREADS, nbnxn_pairlist.h:209)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    return max(1, min(share if share > 0 else avail, avail, 32))
+
+
+def _time_calls(fn, seconds, max_calls=400):
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or n >= max_calls:
+            return n, dt
+
+
+def cpu_baseline(prep, ip, ener, seconds=8.0):
+    """The CPU yardstick north_star names: the reference's SIMD 4xN OpenMP kernel (oracle/_ref/libnbnxn_ref_simd.so,
+    the reference's simd_4xn units compiled for AVX2_256 from where they lie, oracle/ref_simd_harness.c) on the host
+    cores, same atoms and the same atom pairs as the GPU list (as a 4x8 list), same flavour as the timed GPU kernel
+    (analytical Ewald or RF; energies as the GPU step has them), plus its force-only rate.  Bounded sample: repeats
+    for ~`seconds` per figure.  Falls back to the reference's plain-C nbnxn_kernel_ref (oracle/_ref/libnbnxn_ref.so),
+    then to the repo's scalar float port, when the library above it was not built."""
     import oracle as O
+    threads = cpu_threads()
+    host = {"threads": threads, "host_cores": os.cpu_count(), "cores_available": len(os.sched_getaffinity(0)),
+            "survey_simd_4xn_8_threads_pair_per_s": 4.2e9}
+    el = "analytical Ewald" if ip.el_type else "RF"
+    if O.have_ref_simd():
+        rk = O.RefKernelSimd4xN(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip, nlist=threads)
+        pairs = rk.ncj * 32      # its own list: 4x8 cluster pairs x 32 = the GPU list's cluster pairs x 64
+        n, dt = _time_calls(lambda: rk.run(calc_ener=ener, nthreads=threads, outputs=False), seconds)
+        nf, dtf = (n, dt) if not ener else _time_calls(lambda: rk.run(calc_ener=False, nthreads=threads, outputs=False), seconds / 2)
+        rk.close()
+        return dict({"value": pairs * n / dt, "unit": "pair/s", "cores": threads, "kind": "reference",
+                     "kernel": f"nbnxn_kernel_simd_4xn (AVX2_256 4x8, {el}, {'energies' if ener else 'forces only'}, OpenMP)",
+                     "sample": f"{n} calls of the reference's SIMD 4xN kernel ({el}, {'V+F' if ener else 'F'}) on the same {len(prep.xq)} atoms, "
+                               f"{rk.ncj} 4x8 cluster pairs per call over {threads} lists / threads, {dt:.1f} s",
+                     "ms_per_step": 1e3 * dt / n, "force_only_value": pairs * nf / dtf, "force_only_ms_per_step": 1e3 * dtf / nf}, **host)
     if O.have_ref():
-        cores = max(1, min(16, os.cpu_count() or 1))
-        rk = O.RefKernelRef(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip, nlist=cores)
-        rk.run(calc_ener=False, nthreads=cores, outputs=False)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            rk.run(calc_ener=False, nthreads=cores, outputs=False)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > seconds or n >= 200:
-                break
+        rk = O.RefKernelRef(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip, nlist=threads)
+        n, dt = _time_calls(lambda: rk.run(calc_ener=False, nthreads=threads, outputs=False), seconds, 200)
         pairs = rk.ncj * 16      # its own list: 4x4 cluster pairs x 16
-        return {"value": pairs * n / dt, "unit": "pair/s", "cores": cores, "kind": "reference",
-                "sample": f"{n} force-only calls of nbnxn_kernel_ref (plain-C 4x4, {'tabulated Ewald' if ip.el_type else 'RF'}) "
-                          f"on the same {len(prep.xq)} atoms, {rk.ncj} 4x4 cluster pairs per call, {dt:.1f} s",
-                "ms_per_step": 1e3 * dt / n}
+        return dict({"value": pairs * n / dt, "unit": "pair/s", "cores": threads, "kind": "reference",
+                     "kernel": f"nbnxn_kernel_ref (plain-C 4x4, {'tabulated Ewald' if ip.el_type else 'RF'}, forces only, OpenMP)",
+                     "sample": f"{n} force-only calls of nbnxn_kernel_ref (plain-C 4x4, {'tabulated Ewald' if ip.el_type else 'RF'}) "
+                               f"on the same {len(prep.xq)} atoms, {rk.ncj} 4x4 cluster pairs per call, {dt:.1f} s",
+                     "ms_per_step": 1e3 * dt / n}, **host)
     t0 = time.perf_counter()
     O.kernel_gpu_list_f32(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
     dt = time.perf_counter() - t0
-    return {"value": prep.pair_slots / dt, "unit": "pair/s", "cores": 1, "kind": "port",
-            "sample": f"1 force-only call of the scalar float port over the GPU list, {dt:.1f} s", "ms_per_step": 1e3 * dt}
+    return dict({"value": prep.pair_slots / dt, "unit": "pair/s", "cores": 1, "kind": "port", "kernel": "scalar float port of the GPU-layout kernel",
+                 "sample": f"1 force-only call of the scalar float port over the GPU list, {dt:.1f} s", "ms_per_step": 1e3 * dt}, **dict(host, threads=1))
 
 
 def self_launch(nranks, timeout_s=1500):
@@ -370,7 +404,8 @@ def main():
     # figure measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command is kept
     # under profiles/ and quoted only when the workload is the one it was measured on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_i_hbm_traffic.json")
+    tname = "r2_b_hbm_traffic.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
     if not decomposed and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
             and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
@@ -396,19 +431,23 @@ def main():
                             "flops_per_pair": flops_pair}, **cfg_extra),
             "roofline": {"bound": "fp32-vector", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from profiles/r1_i_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+                         "traffic_note": f"HBM bytes per launch from profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                          "kernel_ms": kernel_ms, "kernel_ms_events_raw": kernel_ms_raw, "event_pair_ms": event_pair_ms,
                          "note": "algorithmic flops = pair slots x nrnb.c cost (gmxlib/nrnb.c:101-106); duration = mean HIP-event time around the nonbonded kernel launch inside the timed region minus the latency of an empty event pair"},
         }
         if not args.no_cpu and not decomposed and natoms > 400000:
             # a box of BASELINE configs[3] size: the CPU leg alone (bounded); the full-list oracle pass and the
             # secondary figures belong to the default workload
-            out["cpu_baseline"] = cpu_baseline(prep, ip)
+            out["cpu_baseline"] = cpu_baseline(prep, ip, ener)
         elif not args.no_cpu and not decomposed:
-            cb = cpu_baseline(prep, ip)
+            cb = cpu_baseline(prep, ip, ener)
             out["cpu_baseline"] = cb
             chk = oracle_check(prep, ip, f0, e0)
             out["parity"] = chk
+            # the same kernel time priced over the slots the pruned list still walks (the launch that is timed runs on
+            # the pruned list; `frac` above counts every uploaded slot, the reference's convention)
+            out["roofline"]["frac_post_prune_slots"] = chk["pair_slots_after_prune"] * flops_pair / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS
+            out["roofline"]["frac_pairs_in_cutoff"] = chk["pairs_in_cutoff_non_filler"] * flops_pair / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS
             out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
             out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)

@@ -1062,14 +1062,14 @@ int nbnxn_hip_reset_timings(nbnxn_hip_ptr_t nb)
 
 int nbnxn_hip_min_ci_balanced(nbnxn_hip_ptr_t nb)
 {
-    // The reference asks for 40 entries per multiprocessor (nbnxn_cuda_data_mgmt.cu:76).
-    // One entry is one wave64 here and a CU holds 16 of them (4 per SIMD); measured on the
-    // 97,200-atom water box, 60 per CU (15 per SIMD) is the best trade between the kernel's
-    // tail and the per-entry prologue/epilogue (40: 633, 60: 654, 80: 650 Gpair/s).
+    // The reference asks for 40 entries per multiprocessor (nbnxn_cuda_data_mgmt.cu:76), and 40 per CU is also where
+    // this kernel's trade between the launch's tail and the per-entry prologue / epilogue lies on MI355X: one entry is
+    // one wave64, a CU holds 16 of them.  Measured on the 97,200-atom water box (round 2 kernel, Ewald V+F / RF F
+    // kernel time): 20 per CU 71.6 / 45.8 us, 30: 66.7 / 42.1, 40: 63.7 / 42.9, 60: 65.1 / 45.3, 80: 66.5 / 46.9.
     int        ncu = 256;
     hipDeviceProp_t p;
     if (nb && hipGetDeviceProperties(&p, nb->device) == hipSuccess) { ncu = p.multiProcessorCount; }
-    return 60 * ncu;
+    return 40 * ncu;
 }
 
 int nbnxn_hip_is_kernel_ewald_analytical(const nbnxn_hip_ptr_t nb) { return nb && nb->el_type == NBX_EL_EWALD_ANA; }

@@ -576,9 +576,12 @@ __device__ __forceinline__ float wave_sum_hi(float v)
 #ifndef NBX_KERNEL_WAVES
 #define NBX_KERNEL_WAVES 4
 #endif
+#ifndef NBX_KERNEL_WAVES_F
+#define NBX_KERNEL_WAVES_F 4
+#endif
 
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_KERNEL_WAVES, 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? NBX_KERNEL_WAVES : NBX_KERNEL_WAVES_F, 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
 {
     NBX_KERNEL_ARGS_FROM_PARAMS
     const int lane  = threadIdx.x;

@@ -262,3 +262,59 @@ class RefKernelRef:
 
     def __del__(self):
         self.close()
+
+
+_simd = None
+
+
+def have_ref_simd():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libnbnxn_ref_simd.so"))
+
+
+def simdlib():
+    global _simd
+    if _simd is None:
+        _simd = C.CDLL(os.path.join(_HERE, "_ref", "libnbnxn_ref_simd.so"))
+        _simd.ref_simd_setup.restype = C.c_void_p
+        _simd.ref_simd_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for fn in (_simd.ref_simd_free, _simd.ref_simd_nci, _simd.ref_simd_ncj, _simd.ref_simd_comb_rule):
+            fn.argtypes = [C.c_void_p]
+    return _simd
+
+
+class RefKernelSimd4xN:
+    """The reference's SIMD 4xN OpenMP kernel (AVX2_256: 4x8 cluster pairs, analytical Ewald or RF) on the simple list
+    derived from the GPU list (oracle/ref_simd_harness.c).  The TIMING yardstick of bench.py's cpu_baseline; pins
+    nothing.  nlist lists, one OpenMP thread each at most (nbnxn_kernel_simd_4xn.c:309-311)."""
+
+    def __init__(self, xq, type_, ntype, nbfp, shift_vec, pl, ip, nlist=1):
+        self.n = len(xq)
+        p = ref_params(ip)
+        nbfp = np.ascontiguousarray(nbfp, dtype=np.float32)
+        self.nlist = nlist
+        self.ctx = simdlib().ref_simd_setup(C.c_int(self.n), _p(xq), _p(type_), C.c_int(ntype), _p(nbfp), _p(shift_vec),
+                                            C.c_int(pl.nsci), _p(pl.sci), _p(pl.cj4), _p(pl.excl), C.byref(p), C.c_int(nlist))
+        if not self.ctx:
+            raise RuntimeError("ref_simd_setup refused the input (atoms not a multiple of 8, LJ-PME, or nlist outside 1..32)")
+        self.nci = simdlib().ref_simd_nci(self.ctx)
+        self.ncj = simdlib().ref_simd_ncj(self.ctx)
+        self.comb_rule = simdlib().ref_simd_comb_rule(self.ctx)
+
+    def run(self, calc_ener=True, nthreads=1, outputs=True):
+        if not outputs:
+            simdlib().ref_simd_run(self.ctx, int(calc_ener), nthreads, None, None, None, None)
+            return None
+        f = np.zeros((self.n, 3), dtype=np.float32)
+        fshift = np.zeros((45, 3), dtype=np.float32)
+        vc, vv = C.c_float(0), C.c_float(0)
+        simdlib().ref_simd_run(self.ctx, int(calc_ener), nthreads, _p(f), _p(fshift),
+                               C.cast(C.byref(vc), C.c_void_p), C.cast(C.byref(vv), C.c_void_p))
+        return dict(f=f, fshift=fshift, Vc=vc.value, Vvdw=vv.value)
+
+    def close(self):
+        if self.ctx:
+            simdlib().ref_simd_free(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
