@@ -53,3 +53,32 @@ def test_abi_check_against_reference_headers():
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "ABI check passed" in out.stdout
+
+
+def test_reference_side_binding_compiles_and_links():
+    """include/nbnxn_hip_gmx.h defines the reference's own entry points (nbnxn_cuda_*, gpu_utils, pmalloc) over the
+    library.  Where the reference tree exists the translation unit a maintainer would add is compiled against the
+    reference's prototypes with incompatible pointer types as errors (oracle/binding_check.c, oracle/Makefile) and
+    linked against libnbnxn_hip.so; the program it gives runs the reference's detection call through the binding."""
+    import subprocess
+    ref = "/root/reference/src/gromacs/legacyheaders/nbnxn_cuda_data_mgmt.h"
+    exe = os.path.join(ROOT, "oracle", "_ref", "binding_check")
+    if os.path.exists(ref):
+        r = subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle"), "_ref/binding_check"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "warning" not in (r.stdout + r.stderr)
+    elif not os.path.exists(exe):
+        pytest.skip("oracle/_ref not built (no reference tree here)")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("binding ok")
+    # every reference entry point of INTEGRATION.md section 1 is defined by the binding header
+    text = open(os.path.join(ROOT, "include", "nbnxn_hip_gmx.h")).read()
+    for name in ("nbnxn_cuda_init", "nbnxn_cuda_init_const", "nbnxn_cuda_init_pairlist", "nbnxn_cuda_init_atomdata",
+                 "nbnxn_cuda_pme_loadbal_update_param", "nbnxn_cuda_upload_shiftvec", "nbnxn_cuda_clear_outputs", "nbnxn_cuda_free",
+                 "nbnxn_cuda_get_timings", "nbnxn_cuda_reset_timings", "nbnxn_cuda_min_ci_balanced",
+                 "nbnxn_cuda_is_kernel_ewald_analytical", "nbnxn_cuda_launch_kernel", "nbnxn_cuda_launch_cpyback", "nbnxn_cuda_wait_gpu",
+                 "pmalloc", "pfree", "detect_cuda_gpus", "pick_compatible_gpus", "check_selected_cuda_gpus", "free_gpu_info",
+                 "init_gpu", "free_gpu", "get_current_gpu_device_id", "get_gpu_device_id", "get_gpu_device_info_string",
+                 "sizeof_cuda_dev_info", "do_quick_memtest", "do_full_memtest", "do_timed_memtest"):
+        assert re.search(r"\b" + name + r"\(", text), name
