@@ -110,6 +110,52 @@ def decomposed_step_leg(timeout_s=150):
         return {"error": repr(err)}
 
 
+def pcie_step_leg(g, abi, prep, ip, flags, nsteps=200):
+    """Secondary figure, outside the timed region of `value`: the step through the calls sim_util.c makes, with the
+    reference's calling convention: host xq in, f and energies out EVERY step (clear_outputs -> launch_kernel with host
+    coordinates -> launch_cpyback -> wait_gpu), host arrays pinned as the reference's nbat->alloc hook makes them
+    (nbnxn_hip_pmalloc = pmalloc, forcerec.c:2247-2262).  This is the PCIe-inclusive rate; it is never `value`."""
+    import ctypes as C
+    import time
+    nb = g.gpu.NbnxnHip(0)
+    nb.set_timing(False)
+    g.workload.upload(nb, prep, ip)
+    held = []
+
+    def pinned(shape):
+        n = int(np.prod(shape)) * 4
+        ptr = C.c_void_p()
+        nb.lib.nbnxn_hip_pmalloc(C.byref(ptr), n)
+        if not ptr.value:
+            raise RuntimeError("nbnxn_hip_pmalloc failed")
+        held.append(ptr)
+        return np.frombuffer((C.c_char * n).from_address(ptr.value), dtype=np.float32).reshape(shape)
+
+    xq = pinned(prep.xq.shape)
+    xq[:] = prep.xq
+    f, e_lj, e_el, fsh = pinned((prep.natoms, 3)), pinned((1,)), pinned((1,)), pinned((45, 3))
+
+    def step():
+        nb.clear_outputs(flags)
+        nb.launch_kernel(xq, flags)
+        nb.launch_cpyback(f, flags)
+        nb.wait_gpu(flags, abi.LOCAL, e_lj, e_el, fsh)
+    for _ in range(20):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    ms = (time.perf_counter() - t0) * 1e3 / nsteps
+    del xq, f, e_lj, e_el, fsh
+    for ptr in held:
+        nb.lib.nbnxn_hip_pfree(ptr)
+    nb.close()
+    return {"ms_per_step": ms, "pairs_per_s": prep.pair_slots / (ms * 1e-3), "steps": nsteps,
+            "h2d_bytes_per_step": int(prep.xq.nbytes), "d2h_bytes_per_step": int(prep.natoms * 12 + (2 + 45 * 3) * 4),
+            "note": "clear_outputs -> launch_kernel(host xq) -> launch_cpyback -> wait_gpu every step, pinned host arrays, "
+                    "one blocking wait per step: the reference's calling convention (sim_util.c:622, 1147, 1385)"}
+
+
 def verlet_loop_leg(g, abi, system, ip, flags, nstlist=10, nsteps=100):
     """Secondary figure, outside the timed region of `value`: the whole device-resident step of
     gromacs-cosmo_amd/verlet.py (search on the device every nstlist steps, x gather, kernel, f scatter
@@ -449,6 +495,7 @@ def main():
             out["roofline"]["frac_post_prune_slots"] = chk["pair_slots_after_prune"] * flops_pair / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS
             out["roofline"]["frac_pairs_in_cutoff"] = chk["pairs_in_cutoff_non_filler"] * flops_pair / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS
             out["useful_pairs_per_s"] = chk["pairs_in_cutoff_non_filler"] * args.steps / wall
+            out["pcie_step"] = pcie_step_leg(g, abi, prep, ip, flags)
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
             out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)
             out["decomposed_step_one_rank"] = decomposed_step_leg()

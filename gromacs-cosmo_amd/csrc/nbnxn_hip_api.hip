@@ -556,6 +556,23 @@ void fill_kernel_consts(nbnxn_hip *nb, float rlist, nbx_kernel_k_t &k)
     k.rlist2 = (float)(b * b * (double)rlist * (double)rlist);
 }
 
+// The CUDA module's benchmarking switches (nbnxn_cuda.cu:116-119, applied at :303, :367 and :585): always / never run
+// the energy flavour, always run the pruning flavour, whatever the step's flags and the list's age.  Read once, like
+// the reference's file-scope statics.  They change which kernel runs and what launch_cpyback copies, not what
+// wait_gpu hands out (that follows the caller's flags, as in the reference).
+struct BenchSwitches { bool always_ener, never_ener, always_prune; };
+const BenchSwitches &bench_switches()
+{
+    static const BenchSwitches s = {getenv("GMX_GPU_ALWAYS_ENER") != nullptr, getenv("GMX_GPU_NEVER_ENER") != nullptr,
+                                    getenv("GMX_GPU_ALWAYS_PRUNE") != nullptr};
+    return s;
+}
+inline bool kernel_calc_ener(int flags)
+{
+    const BenchSwitches &b = bench_switches();
+    return (((flags & NBX_FORCE_VIRIAL) != 0) || b.always_ener) && !b.never_ener;
+}
+
 int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
 {
     if (check_loc(iloc)) { return 1; }
@@ -565,7 +582,7 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     if (pl.nsci == 0) { return 0; }
     if (!nb->shift_vec_uploaded) { return nbx_fail("launch before upload_shiftvec"); }
     hipStream_t st = nb->stream[iloc];
-    const bool  ener = (flags & NBX_FORCE_VIRIAL) != 0;   // energies and shift forces go together (:298-299)
+    const bool  ener = kernel_calc_ener(flags);   // energies and shift forces go together (:298-299)
     int         begin, len;
     loc_range(nb, iloc, &begin, &len);
 
@@ -602,7 +619,8 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
     fill_kernel_consts(nb, pl.rlist, a.k);
 
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_start[iloc], st)); }
-    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, pl.do_prune, nb->rvdw < nb->rcoulomb, nb->vdw_mod, st));
+    const bool prune = pl.do_prune || bench_switches().always_prune;   // nbnxn_cuda.cu:367
+    HIP_TRY(nbx_launch_nonbonded(a, pl.nsci, nb->el_type, ener, prune, nb->rvdw < nb->rcoulomb, nb->vdw_mod, st));
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->k_stop[iloc], st)); nb->k_timed[iloc] = true; }
     nb->last_ener[iloc] = ener; nb->last_prune[iloc] = pl.do_prune;
     if (a.zero) { nb->clean_other = true; }
@@ -615,7 +633,7 @@ int cpyback_impl(nbnxn_hip *nb, float *h_f, int flags, int aloc)
     const int iloc = aloc;
     if (nb->plist[iloc].nsci == 0) { return 0; }
     hipStream_t st = nb->stream[iloc];
-    const bool  ener = (flags & NBX_FORCE_VIRIAL) != 0;
+    const bool  ener = kernel_calc_ener(flags);   // nbnxn_cuda.cu:585
     int         begin, len;
     loc_range(nb, aloc, &begin, &len);
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->d2h_start[iloc], st)); }
