@@ -299,6 +299,8 @@ def main():
     ap.add_argument("--mcb", type=int, default=-1, help="list split target (-1: nbnxn_hip_min_ci_balanced)")
     ap.add_argument("--precondition", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up steps, so that the timed region runs at the clock the GPU sustains")
+    ap.add_argument("--dd-grid", default="", help="ranks along x,y,z (default 1,1,N: z slabs); e.g. 2,2,2 for --gpus 8")
+    ap.add_argument("--dd-self-dims", default="2", help="with --dd-self: the dimensions the one rank is its own neighbour in (0,1,2 = the 13-message step)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --tiles is the whole box, cut into --gpus slabs (default: --tiles per GPU)")
     args = ap.parse_args()
@@ -379,7 +381,10 @@ def main():
         # (nbnxn_hip_dd_*); BENCH_DD_TORCH=1 (and the one-GPU rehearsal, where RCCL cannot run two ranks on one
         # device) sends them through torch.distributed instead
         rccl_direct = not rehearsal and os.environ.get("BENCH_DD_TORCH") != "1"
-        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong)
+        grid = tuple(int(v) for v in args.dd_grid.split(",")) if args.dd_grid else (1, 1, world)
+        self_dims = tuple(int(v) for v in args.dd_self_dims.split(",")) if args.dd_self else ()
+        run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong, grid=grid,
+                         self_dims=self_dims)
         rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
@@ -388,7 +393,8 @@ def main():
         step = run.step          # step(ev) records ev around the local kernel
         stream = torch.cuda.ExternalStream(run.nb.stream(abi.LOCAL))
         sync = lambda: torch.cuda.synchronize()
-        parallelism = f"dd{world}{' (one rank, its own neighbour)' if world == 1 else ''} (z slabs, RCCL halo x/f " + ("issued by the HIP module)" if rccl_direct else "through torch.distributed)")
+        shape = "z slabs" if grid == (1, 1, world) and self_dims in ((), (2,)) else f"{grid[0]}x{grid[1]}x{grid[2]} bricks, half shell, {len(run.dom.msgs)} direct peers' messages"
+        parallelism = f"dd{world}{' (one rank, its own neighbour)' if world == 1 else ''} ({shape}, RCCL halo x/f " + ("issued by the HIP module)" if rccl_direct else "through torch.distributed)")
         cfg_extra = run.describe()
         if args.mcb >= 0 or args.variant >= 0 or args.no_split:
             raise SystemExit("--mcb/--variant/--no-split are single-GPU A/B switches")
@@ -469,7 +475,7 @@ def main():
             "ns_per_day": 86400.0 * DT_FS * 1e-6 / (ms_per_step * 1e-3),
             "ns_per_day_note": f"nonbonded only, dt = {DT_FS} fs",
             "config": dict({"workload": f"{model.upper()} water {natoms} atoms ({'x'.join(map(str, tiles))} spc216 tiles"
-                                        f"{' per GPU' if world > 1 and not args.strong else ''}{', one box cut into ' + str(world) + ' z slabs' if world > 1 and args.strong else ''}), "
+                                        f"{' per GPU' if world > 1 and not args.strong else ''}{', one box cut into ' + (str(world) + ' z slabs' if not args.dd_grid else args.dd_grid.replace(',', 'x') + ' bricks') if world > 1 and args.strong else ''}), "
                                         f"{'analytical Ewald real-space' if args.workload == 'ewald' else 'reaction-field'} + LJ, "
                                         f"rc=rlist=1.0 nm, {'energies+virial every step' if ener else 'forces only'}",
                             "parallelism": parallelism, "pair_slots_per_step": pair_slots,

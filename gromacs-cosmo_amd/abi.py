@@ -22,6 +22,8 @@ LOCAL, NONLOCAL = 0, 1
 # accumulation slots of the device output buffer (csrc/nbnxn_kernel.h)
 OUT_SLOTS, OUT_STRIDE = 64, 144
 DD_UNIQUE_ID_BYTES = 128   # NBX_DD_UNIQUE_ID_BYTES
+MAX_ZONES = 14             # NBX_MAX_ZONES
+DD_MAX_MESSAGES = 13       # NBX_DD_MAX_MESSAGES
 EL_RF, EL_EWALD_ANA, EL_EWALD_TAB = 0, 1, 2
 EEL_CUT, EEL_RF, EEL_GRF, EEL_PME, EEL_EWALD = 0, 1, 2, 3, 4
 VDW_CUT, VDW_PME = 0, 5
@@ -175,6 +177,12 @@ class GpuDevInfo(C.Structure):
 
 
 GPU_COMPATIBLE, GPU_NONEXISTENT, GPU_INCOMPATIBLE, GPU_INSANE = 0, 1, 2, 3
+
+
+class DdMessage(C.Structure):
+    """nbx_dd_message_t (include/nbnxn_hip.h)"""
+    _fields_ = [("send_to", C.c_int), ("recv_from", C.c_int), ("n_send", C.c_int), ("n_recv", C.c_int),
+                ("shift_index", C.c_int), ("shift", C.c_float * 3)]
 
 
 class GridZone(C.Structure):

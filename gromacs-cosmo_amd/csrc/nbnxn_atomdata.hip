@@ -66,7 +66,9 @@ __global__ void __launch_bounds__(64) nbnxn_halo_unpack_x(const int *__restrict_
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) { return; }
-    xq[slot[i]] = buf[i];
+    const int s = slot[i];
+    if (s < 0) { return; }          // padding row of a multi-message layout
+    xq[s] = buf[i];
 }
 
 __global__ void __launch_bounds__(64) nbnxn_halo_pack_f(const int *__restrict__ slot, int n, const float *__restrict__ f,
@@ -75,6 +77,7 @@ __global__ void __launch_bounds__(64) nbnxn_halo_pack_f(const int *__restrict__ 
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) { return; }
     const int s = slot[i];
+    if (s < 0) { return; }          // padding row of a multi-message layout
     buf[3 * i + 0] = f[3 * s + 0];
     buf[3 * i + 1] = f[3 * s + 1];
     buf[3 * i + 2] = f[3 * s + 2];
@@ -114,6 +117,57 @@ __global__ void __launch_bounds__(64) nbnxn_halo_unpack_f(const int *__restrict_
     }
 }
 
+// Several messages in one launch (nbnxn_hip_dd_set_messages): the rows of message k start at a multiple of 64, so a wave
+// belongs to one message (wave_msg[wave]) and its shift / shift-force entry are wave-uniform; rows that pad a message
+// to the next multiple of 64 have slot -1.  msg_shift[k] = {shift x, y, z, shift index as int bits (-1 = none)}.
+__global__ void __launch_bounds__(64) nbnxn_halo_pack_x_msgs(const int *__restrict__ slot, int n, const float4 *__restrict__ xq,
+                                                              const int *__restrict__ wave_msg, const float4 *__restrict__ msg_shift,
+                                                              float4 *__restrict__ buf)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) { return; }
+    const int s = slot[i];
+    if (s < 0) { return; }
+    const float4 sh = msg_shift[wave_msg[blockIdx.x]];
+    float4       v  = xq[s];
+    v.x += sh.x; v.y += sh.y; v.z += sh.z;
+    buf[i] = v;
+}
+
+__global__ void __launch_bounds__(64) nbnxn_halo_unpack_f_msgs(const int *__restrict__ slot, int n, const float *__restrict__ buf,
+                                                                float *__restrict__ f, const int *__restrict__ wave_msg,
+                                                                const float4 *__restrict__ msg_shift, float *__restrict__ out)
+{
+    const int i  = blockIdx.x * 64 + threadIdx.x;
+    float     fx = 0, fy = 0, fz = 0;
+    const int s  = i < n ? slot[i] : -1;
+    if (s >= 0)
+    {
+        fx = buf[3 * i + 0]; fy = buf[3 * i + 1]; fz = buf[3 * i + 2];
+        atomicAdd(f + 3 * s + 0, fx);
+        atomicAdd(f + 3 * s + 1, fy);
+        atomicAdd(f + 3 * s + 2, fz);
+    }
+    const int is = __float_as_int(msg_shift[wave_msg[blockIdx.x]].w);   // wave-uniform
+    if (is >= 0)
+    {
+        double dx = fx, dy = fy, dz = fz;
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            dx += __shfl_down(dx, o);
+            dy += __shfl_down(dy, o);
+            dz += __shfl_down(dz, o);
+        }
+        if (threadIdx.x == 0)
+        {
+            float *entry = out + 2 + 3 * is;      // accumulation slot 0: {e_lj, e_el, fshift[45][3]}
+            atomicAdd(entry + 0, (float)dx);
+            atomicAdd(entry + 1, (float)dy);
+            atomicAdd(entry + 2, (float)dz);
+        }
+    }
+}
+
 } // namespace
 
 hipError_t nbx_launch_halo_pack_x(const int *slot, int n, const float4 *xq, const float *shift, float4 *buf, hipStream_t stream)
@@ -142,6 +196,22 @@ hipError_t nbx_launch_halo_unpack_f(const int *slot, int n, const float *buf, fl
     if (n <= 0) { return hipSuccess; }
     if (fshift_entry) { hipLaunchKernelGGL(nbnxn_halo_unpack_f<true>, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, buf, f, fshift_entry); }
     else { hipLaunchKernelGGL(nbnxn_halo_unpack_f<false>, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, buf, f, fshift_entry); }
+    return hipGetLastError();
+}
+
+hipError_t nbx_launch_halo_pack_x_msgs(const int *slot, int n, const float4 *xq, const int *wave_msg, const float4 *msg_shift, float4 *buf,
+                                       hipStream_t stream)
+{
+    if (n <= 0) { return hipSuccess; }
+    hipLaunchKernelGGL(nbnxn_halo_pack_x_msgs, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, xq, wave_msg, msg_shift, buf);
+    return hipGetLastError();
+}
+
+hipError_t nbx_launch_halo_unpack_f_msgs(const int *slot, int n, const float *buf, float *f, const int *wave_msg, const float4 *msg_shift,
+                                         float *out, hipStream_t stream)
+{
+    if (n <= 0) { return hipSuccess; }
+    hipLaunchKernelGGL(nbnxn_halo_unpack_f_msgs, dim3((n + 63) / 64), dim3(64), 0, stream, slot, n, buf, f, wave_msg, msg_shift, out);
     return hipGetLastError();
 }
 

@@ -209,11 +209,14 @@ struct nbnxn_hip {
     // domain decomposition over RCCL (nbnxn_hip_dd_*): one pulse along one dimension
     ncclComm_t    dd_comm = nullptr;
     int           dd_rank = -1, dd_nranks = 0;
-    int           dd_send_to = -1, dd_recv_from = -1;   // coordinates go to send_to, forces come back from it
-    int           dd_n_send = 0, dd_n_recv = 0, dd_shift_index = -1;
-    float         dd_shift[3] = {0, 0, 0};
-    bool          dd_have_pulse = false;
-    DevBuf<int>   dd_send_slots, dd_recv_slots;
+    // the halo messages of a step (nbnxn_hip_dd_set_messages): rows of message k start at dd_send_off[k] / dd_recv_off[k]
+    // (multiples of 64) in the slot lists and buffers; coordinates go to send_to, forces come back from it
+    int              dd_nmsg = 0;
+    nbx_dd_message_t dd_msg[NBX_DD_MAX_MESSAGES];
+    int              dd_send_off[NBX_DD_MAX_MESSAGES], dd_recv_off[NBX_DD_MAX_MESSAGES];
+    int              dd_send_rows = 0, dd_recv_rows = 0;   // padded totals
+    DevBuf<int>      dd_send_slots, dd_recv_slots, dd_send_wave_msg;
+    DevBuf<float>    dd_msg_shift;                         // float4 per message: shift, shift index as int bits
     DevBuf<float> dd_x_out, dd_x_in, dd_f_out, dd_f_in;
 
     nbx_wallclock_gpu_t timings;
@@ -1350,7 +1353,7 @@ int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[9], const in
     if (check_handle(nb)) { return 1; }
     if (!nb->have_const) { return nbx_fail("put_on_grid before init_const (the number of atom types comes from there)"); }
     if (natoms <= 0 || !box || !x || !zones) { return nbx_fail("put_on_grid: missing atoms, box or zones"); }
-    if (nzones < 1 || nzones > 8) { return nbx_fail("put_on_grid: %d zones (a domain decomposition has 1 to 8)", nzones); }
+    if (nzones < 1 || nzones > NBX_MAX_ZONES) { return nbx_fail("put_on_grid: %d zones (a domain decomposition has 1 to %d)", nzones, NBX_MAX_ZONES); }
     if ((type == nullptr) != (q == nullptr)) { return nbx_fail("put_on_grid: types and charges come together"); }
     // the topology does not change between searches: NULL type / q reuse the arrays of the last call
     if (!type && ((int)nb->d_type_in.n != natoms || (int)nb->d_q_in.n != natoms))
@@ -1828,74 +1831,122 @@ int nbnxn_hip_dd_finish(nbnxn_hip_ptr_t nb)
         (void)g_rccl.CommDestroy(nb->dd_comm);
         nb->dd_comm = nullptr;
     }
-    dev_free(nb->dd_send_slots); dev_free(nb->dd_recv_slots);
+    dev_free(nb->dd_send_slots); dev_free(nb->dd_recv_slots); dev_free(nb->dd_send_wave_msg); dev_free(nb->dd_msg_shift);
     dev_free(nb->dd_x_out); dev_free(nb->dd_x_in); dev_free(nb->dd_f_out); dev_free(nb->dd_f_in);
-    nb->dd_have_pulse = false;
+    nb->dd_nmsg = 0;
+    return 0;
+}
+
+int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message_t *msg, const int *send_slots, const int *recv_slots)
+{
+    if (check_dd(nb)) { return 1; }
+    if (nmsg < 1 || nmsg > NBX_DD_MAX_MESSAGES || !msg) { return nbx_fail("dd_set_messages: %d messages (1 to %d)", nmsg, NBX_DD_MAX_MESSAGES); }
+    if (!nb->xq.p || !nb->f.p) { return nbx_fail("dd_set_messages before the atom data exists"); }
+    // padded layouts: every message starts at a multiple of 64 rows, so that one wave of the pack / unpack kernels
+    // belongs to one message
+    std::vector<int> h_send, h_recv, h_wave;
+    std::vector<float> h_shift((size_t)nmsg * 4);
+    size_t si = 0, ri = 0;
+    for (int k = 0; k < nmsg; k++)
+    {
+        const nbx_dd_message_t &m = msg[k];
+        if (m.send_to < 0 || m.send_to >= nb->dd_nranks || m.recv_from < 0 || m.recv_from >= nb->dd_nranks)
+        {
+            return nbx_fail("dd_set_messages: message %d has neighbours %d / %d outside [0, %d)", k, m.send_to, m.recv_from, nb->dd_nranks);
+        }
+        if (m.n_send < 0 || m.n_recv < 0 || m.n_send > nb->natoms || m.n_recv > nb->natoms || (m.n_send > 0 && !send_slots) || (m.n_recv > 0 && !recv_slots))
+        {
+            return nbx_fail("dd_set_messages: message %d moves %d / %d halo atoms on a grid of %d slots", k, m.n_send, m.n_recv, nb->natoms);
+        }
+        if (m.shift_index < -1 || m.shift_index >= NBX_SHIFTS) { return nbx_fail("dd_set_messages: shift index %d outside [-1, %d)", m.shift_index, NBX_SHIFTS); }
+        nb->dd_send_off[k] = (int)h_send.size(); nb->dd_recv_off[k] = (int)h_recv.size();
+        for (int i = 0; i < m.n_send; i++, si++)
+        {
+            if (send_slots[si] < 0 || send_slots[si] >= nb->natoms) { return nbx_fail("dd_set_messages: send slot %d outside the grid", send_slots[si]); }
+            h_send.push_back(send_slots[si]);
+        }
+        for (int i = 0; i < m.n_recv; i++, ri++)
+        {
+            if (recv_slots[ri] < 0 || recv_slots[ri] >= nb->natoms) { return nbx_fail("dd_set_messages: receive slot %d outside the grid", recv_slots[ri]); }
+            h_recv.push_back(recv_slots[ri]);
+        }
+        while (h_send.size() % 64) { h_send.push_back(-1); }
+        while (h_recv.size() % 64) { h_recv.push_back(-1); }
+        h_wave.resize(h_send.size() / 64, k);
+        int is = m.shift_index;
+        memcpy(&h_shift[4 * k], m.shift, 3 * sizeof(float));
+        memcpy(&h_shift[4 * k + 3], &is, sizeof(int));
+        nb->dd_msg[k] = m;
+    }
+    HIP_TRY(hipSetDevice(nb->device));
+    hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
+    const size_t ns = std::max<size_t>(h_send.size(), 64), nr = std::max<size_t>(h_recv.size(), 64);
+    if (dev_reserve(nb->dd_send_slots, ns) || dev_reserve(nb->dd_recv_slots, nr) || dev_reserve(nb->dd_send_wave_msg, ns / 64)
+        || dev_reserve(nb->dd_msg_shift, (size_t)NBX_DD_MAX_MESSAGES * 4)
+        || dev_reserve(nb->dd_x_out, ns * 4) || dev_reserve(nb->dd_x_in, nr * 4) || dev_reserve(nb->dd_f_out, nr * 3) || dev_reserve(nb->dd_f_in, ns * 3)) { return 1; }
+    // the steps in flight still read the old lists
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!h_send.empty()) { HIP_TRY(hipMemcpyAsync(nb->dd_send_slots.p, h_send.data(), h_send.size() * sizeof(int), hipMemcpyHostToDevice, st)); }
+    if (!h_recv.empty()) { HIP_TRY(hipMemcpyAsync(nb->dd_recv_slots.p, h_recv.data(), h_recv.size() * sizeof(int), hipMemcpyHostToDevice, st)); }
+    if (!h_wave.empty()) { HIP_TRY(hipMemcpyAsync(nb->dd_send_wave_msg.p, h_wave.data(), h_wave.size() * sizeof(int), hipMemcpyHostToDevice, st)); }
+    HIP_TRY(hipMemcpyAsync(nb->dd_msg_shift.p, h_shift.data(), h_shift.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    nb->dd_send_rows = (int)h_send.size(); nb->dd_recv_rows = (int)h_recv.size();
+    nb->dd_nmsg = nmsg;
     return 0;
 }
 
 int nbnxn_hip_dd_set_pulse(nbnxn_hip_ptr_t nb, int send_to, int recv_from, const int *send_slots, int n_send,
                            const int *recv_slots, int n_recv, const float *shift, int shift_index)
 {
-    if (check_dd(nb)) { return 1; }
-    if (send_to < 0 || send_to >= nb->dd_nranks || recv_from < 0 || recv_from >= nb->dd_nranks)
-    {
-        return nbx_fail("dd_set_pulse: neighbours %d / %d outside [0, %d)", send_to, recv_from, nb->dd_nranks);
-    }
-    if (n_send < 0 || n_recv < 0 || n_send > nb->natoms || n_recv > nb->natoms || (n_send > 0 && !send_slots) || (n_recv > 0 && !recv_slots))
-    {
-        return nbx_fail("dd_set_pulse: %d / %d halo atoms on a grid of %d slots", n_send, n_recv, nb->natoms);
-    }
-    if (shift_index < -1 || shift_index >= NBX_SHIFTS) { return nbx_fail("shift index %d outside [-1, %d)", shift_index, NBX_SHIFTS); }
-    for (int i = 0; i < n_send; i++) { if (send_slots[i] < 0 || send_slots[i] >= nb->natoms) { return nbx_fail("dd_set_pulse: send slot %d outside the grid", send_slots[i]); } }
-    for (int i = 0; i < n_recv; i++) { if (recv_slots[i] < 0 || recv_slots[i] >= nb->natoms) { return nbx_fail("dd_set_pulse: receive slot %d outside the grid", recv_slots[i]); } }
-    HIP_TRY(hipSetDevice(nb->device));
-    hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
-    if (dev_reserve(nb->dd_send_slots, std::max(n_send, 1)) || dev_reserve(nb->dd_recv_slots, std::max(n_recv, 1))
-        || dev_reserve(nb->dd_x_out, (size_t)std::max(n_send, 1) * 4) || dev_reserve(nb->dd_x_in, (size_t)std::max(n_recv, 1) * 4)
-        || dev_reserve(nb->dd_f_out, (size_t)std::max(n_recv, 1) * 3) || dev_reserve(nb->dd_f_in, (size_t)std::max(n_send, 1) * 3)) { return 1; }
-    if (n_send > 0) { HIP_TRY(hipMemcpyAsync(nb->dd_send_slots.p, send_slots, (size_t)n_send * sizeof(int), hipMemcpyHostToDevice, st)); }
-    if (n_recv > 0) { HIP_TRY(hipMemcpyAsync(nb->dd_recv_slots.p, recv_slots, (size_t)n_recv * sizeof(int), hipMemcpyHostToDevice, st)); }
-    HIP_TRY(hipStreamSynchronize(st));
-    nb->dd_send_to = send_to; nb->dd_recv_from = recv_from;
-    nb->dd_n_send = n_send; nb->dd_n_recv = n_recv;
-    for (int d = 0; d < 3; d++) { nb->dd_shift[d] = shift ? shift[d] : 0.0f; }
-    nb->dd_shift_index = shift_index;
-    nb->dd_have_pulse  = true;
-    return 0;
+    // one pulse along one dimension = one message
+    nbx_dd_message_t m;
+    m.send_to = send_to; m.recv_from = recv_from; m.n_send = n_send; m.n_recv = n_recv; m.shift_index = shift_index;
+    for (int d = 0; d < 3; d++) { m.shift[d] = shift ? shift[d] : 0.0f; }
+    return nbnxn_hip_dd_set_messages(nb, 1, &m, send_slots, recv_slots);
 }
 
 int nbnxn_hip_dd_move_x(nbnxn_hip_ptr_t nb)
 {
     if (check_dd(nb)) { return 1; }
-    if (!nb->dd_have_pulse) { return nbx_fail("dd_move_x before dd_set_pulse"); }
+    if (nb->dd_nmsg == 0) { return nbx_fail("dd_move_x before dd_set_pulse / dd_set_messages"); }
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
     // the home coordinates the pack kernel reads may still be on their way on the local stream (x gather, H2D)
     if (wait_x_written(nb, st)) { return 1; }
-    HIP_TRY(nbx_launch_halo_pack_x(nb->dd_send_slots.p, nb->dd_n_send, nb->xq.p, nb->dd_shift, reinterpret_cast<float4 *>(nb->dd_x_out.p), st));
+    HIP_TRY(nbx_launch_halo_pack_x_msgs(nb->dd_send_slots.p, nb->dd_send_rows, nb->xq.p, nb->dd_send_wave_msg.p,
+                                        reinterpret_cast<const float4 *>(nb->dd_msg_shift.p), reinterpret_cast<float4 *>(nb->dd_x_out.p), st));
     RCCL_TRY(g_rccl.GroupStart());
-    if (nb->dd_n_send > 0) { RCCL_TRY(g_rccl.Send(nb->dd_x_out.p, (size_t)nb->dd_n_send * 4, ncclFloat, nb->dd_send_to, nb->dd_comm, st)); }
-    if (nb->dd_n_recv > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_x_in.p, (size_t)nb->dd_n_recv * 4, ncclFloat, nb->dd_recv_from, nb->dd_comm, st)); }
+    for (int k = 0; k < nb->dd_nmsg; k++)
+    {
+        const nbx_dd_message_t &m = nb->dd_msg[k];
+        if (m.n_send > 0) { RCCL_TRY(g_rccl.Send(nb->dd_x_out.p + (size_t)nb->dd_send_off[k] * 4, (size_t)m.n_send * 4, ncclFloat, m.send_to, nb->dd_comm, st)); }
+        if (m.n_recv > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_x_in.p + (size_t)nb->dd_recv_off[k] * 4, (size_t)m.n_recv * 4, ncclFloat, m.recv_from, nb->dd_comm, st)); }
+    }
     RCCL_TRY(g_rccl.GroupEnd());
-    HIP_TRY(nbx_launch_halo_unpack_x(nb->dd_recv_slots.p, nb->dd_n_recv, reinterpret_cast<const float4 *>(nb->dd_x_in.p), nb->xq.p, st));
+    HIP_TRY(nbx_launch_halo_unpack_x(nb->dd_recv_slots.p, nb->dd_recv_rows, reinterpret_cast<const float4 *>(nb->dd_x_in.p), nb->xq.p, st));
     return 0;
 }
 
 int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb)
 {
     if (check_dd(nb)) { return 1; }
-    if (!nb->dd_have_pulse) { return nbx_fail("dd_move_f before dd_set_pulse"); }
+    if (nb->dd_nmsg == 0) { return nbx_fail("dd_move_f before dd_set_pulse / dd_set_messages"); }
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
-    HIP_TRY(nbx_launch_halo_pack_f(nb->dd_recv_slots.p, nb->dd_n_recv, nb->f.p, nb->dd_f_out.p, st));
+    HIP_TRY(nbx_launch_halo_pack_f(nb->dd_recv_slots.p, nb->dd_recv_rows, nb->f.p, nb->dd_f_out.p, st));
     // the reverse path: forces on imported atoms go back to where the coordinates came from
     RCCL_TRY(g_rccl.GroupStart());
-    if (nb->dd_n_recv > 0) { RCCL_TRY(g_rccl.Send(nb->dd_f_out.p, (size_t)nb->dd_n_recv * 3, ncclFloat, nb->dd_recv_from, nb->dd_comm, st)); }
-    if (nb->dd_n_send > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_f_in.p, (size_t)nb->dd_n_send * 3, ncclFloat, nb->dd_send_to, nb->dd_comm, st)); }
+    for (int k = 0; k < nb->dd_nmsg; k++)
+    {
+        const nbx_dd_message_t &m = nb->dd_msg[k];
+        if (m.n_recv > 0) { RCCL_TRY(g_rccl.Send(nb->dd_f_out.p + (size_t)nb->dd_recv_off[k] * 3, (size_t)m.n_recv * 3, ncclFloat, m.recv_from, nb->dd_comm, st)); }
+        if (m.n_send > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_f_in.p + (size_t)nb->dd_send_off[k] * 3, (size_t)m.n_send * 3, ncclFloat, m.send_to, nb->dd_comm, st)); }
+    }
     RCCL_TRY(g_rccl.GroupEnd());
-    float *entry = nb->dd_shift_index >= 0 ? nb->out + 2 + 3 * nb->dd_shift_index : nullptr;
-    HIP_TRY(nbx_launch_halo_unpack_f(nb->dd_send_slots.p, nb->dd_n_send, nb->dd_f_in.p, nb->f.p, entry, st));
+    // into accumulation slot 0 of the output in use for the messages that crossed a periodic boundary
+    HIP_TRY(nbx_launch_halo_unpack_f_msgs(nb->dd_send_slots.p, nb->dd_send_rows, nb->dd_f_in.p, nb->f.p, nb->dd_send_wave_msg.p,
+                                          reinterpret_cast<const float4 *>(nb->dd_msg_shift.p), nb->out, st));
     return 0;
 }
 

@@ -99,5 +99,10 @@ hipError_t nbx_launch_halo_pack_x(const int *slot, int n, const float4 *xq, cons
 hipError_t nbx_launch_halo_unpack_x(const int *slot, int n, const float4 *buf, float4 *xq, hipStream_t stream);
 hipError_t nbx_launch_halo_pack_f(const int *slot, int n, const float *f, float *buf, hipStream_t stream);
 hipError_t nbx_launch_halo_unpack_f(const int *slot, int n, const float *buf, float *f, float *fshift_entry, hipStream_t stream);
+// several messages in one launch: rows of a message start at a multiple of 64, padding rows have slot -1
+hipError_t nbx_launch_halo_pack_x_msgs(const int *slot, int n, const float4 *xq, const int *wave_msg, const float4 *msg_shift, float4 *buf,
+                                       hipStream_t stream);
+hipError_t nbx_launch_halo_unpack_f_msgs(const int *slot, int n, const float *buf, float *f, const int *wave_msg, const float4 *msg_shift,
+                                         float *out, hipStream_t stream);
 
 #endif

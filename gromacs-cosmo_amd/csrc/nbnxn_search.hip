@@ -76,7 +76,9 @@ struct GridDims {
     float sx, sy, inv_sx, inv_sy;
 };
 
-constexpr int MAX_ZONES = 8;   // a 3-D domain decomposition has at most 8 (domdec.c:433-449)
+// home + halo zones: the reference's eighth-shell decomposition has at most 8 (domdec.c:433-449); the half-shell
+// decomposition with direct peers of gromacs-cosmo_amd/dd.py has 1 + 13 in three dimensions
+constexpr int MAX_ZONES = NBX_MAX_ZONES;
 
 // what the list kernels need to know about one j-zone
 struct ZoneParams {
@@ -1101,8 +1103,8 @@ int nbx_search_grid_fill(nbx_search *s, hipStream_t st, int zone, const float *d
         const size_t npad = (size_t)s->nc * NA_SC;
         if (s->a.reserve(npad) || s->cell.reserve(s->natoms) || s->nsubc.reserve(s->nc) || s->bb.reserve((size_t)s->nc * NSUBC * 6)
             || s->bbcz.reserve((size_t)s->nc * 2) || s->bbsc.reserve((size_t)s->nc * 6) || s->zrange.reserve(2 * MAX_ZONES)) { return 1; }
-        static const unsigned init[2 * MAX_ZONES] = {0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u,
-                                                     0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u};
+        static unsigned init[2 * MAX_ZONES];   // {min = all ones, max = 0} per zone
+        for (int i = 0; i < MAX_ZONES; i++) { init[2 * i] = 0xffffffffu; init[2 * i + 1] = 0u; }
         S_TRY(hipMemcpyAsync(s->zrange.p, init, sizeof(init), hipMemcpyHostToDevice, st));
     }
     Zone &z = s->zone[zone];

@@ -1,30 +1,42 @@
-"""1-D slab domain decomposition of the Verlet nonbonded path, one process per GPU.
+"""Spatial domain decomposition of the Verlet nonbonded path, one process per GPU: z slabs by default, bricks in two
+or three dimensions on request.
 
 The reference decomposes space (mdlib/domdec.c) and computes non-local pairs on the GPU in a
 second stream (sim_util.c:1012-1212: local launch, halo x, non-local launch, copy-backs,
-halo f).  The path's multi-GPU form here is the smallest scheme with the same data flow:
+halo f).  The path's multi-GPU form here has the same data flow with a simpler zone scheme:
 
-  * z slabs of equal thickness, rank r owns z in [r Lz, (r+1) Lz); x and y stay periodic
-    inside the search, z is decomposed (no periodic shift along z: nbnxn_search.c:4906-4927);
-  * half shell: rank r imports the atoms of rank r+1 that lie within rlist above its upper
-    face (zone 1 of its grid) and computes home x halo pairs in the NON-LOCAL list; home x home
-    pairs are the LOCAL list.  Slabs must be thicker than rlist so that only neighbours interact;
-  * per step: halo coordinates travel DOWN (r -> r-1), halo forces travel UP (r -> r+1) and are
-    added to the owner's forces; {e_lj, e_el, fshift} are summed over ranks.
+  * the box is cut into grid = (nx, ny, nz) bricks of equal size (default (1, 1, world): z slabs); a dimension that
+    is not cut stays periodic inside the search, a cut one gets no periodic shift there (nbnxn_search.c:4906-4927);
+  * half shell with direct peers: a rank imports, from each of its "forward" neighbours (offsets (dx, dy, dz) in
+    {-1, 0, 1}^3 over the cut dimensions with (dz, dy, dx) > (0, 0, 0): 1, 4 or 13 of them), the atoms within rlist
+    of the face, edge or corner it shares with that neighbour.  Each import is one grid zone and one message straight
+    from the rank that owns the atoms.  Home x halo pairs are the NON-LOCAL list, home x home pairs the LOCAL list;
+    the i-clusters of both are home clusters, so no pair is ever computed between two imported zones.  Every pair of
+    atoms in different bricks is seen by exactly one of the two ranks: the one for which the other is forward.
+    The reference's eighth shell (dd_zo / dd_zp3, domdec.c:433-449) imports from 7 zones in staged pulses that
+    forward corner data through intermediate ranks (domdec.c:667-758) and computes zone x zone pairs; on a node
+    whose 8 GPUs are all linked to each other every neighbour is one hop away, the faces carry nearly all of the
+    volume in both schemes (13x13x14 tiles on 2x2x2 ranks: 27 % of the home atoms here, 25 % there), and one grouped
+    RCCL call moves all messages at once.  Bricks must be thicker than rlist so that only neighbours interact;
+  * per step: halo coordinates travel to the ranks that import them (plus the box vectors of the periodic
+    boundaries they cross), halo forces travel back and are added to the owner's forces -- those that crossed a
+    boundary also to the shift force of that crossing, the rule of dd_move_f (domdec.c:837-851); {e_lj, e_el,
+    fshift} are summed over ranks.
 
 Three ways to move the halo, one data flow:
-  * `RcclHalo` (what bench.py --gpus N uses): the HIP module issues pack kernel, grouped RCCL send / receive and
+  * `RcclHalo` (what bench.py --gpus N uses): the HIP module issues pack kernel, grouped RCCL sends / receives and
     unpack kernel itself on its non-local stream (nbnxn_hip_dd_*, its own communicator);
   * `DeviceHalo`: the module's pack / unpack kernels, the messages through torch.distributed (backend "nccl" = RCCL
     over xGMI on the GPU box, "gloo" in rehearsals on one GPU);
   * `HaloExchange`: torch indexing operations and torch.distributed, on CPU and GPU tensors alike -- what
     tests/test_dd_cpu.py binds to the oracle.
 `SlabRun` binds them to the HIP module (device buffers wrapped in place, local / non-local HIP streams).  One rank is
-a valid decomposition too: it is its own neighbour, periodic in z through a halo of its own atoms.
+a valid decomposition too: it is its own neighbour, periodic through a halo of its own atoms in the dimensions
+named by `self_dims` (z by default; all three give the 13-message step on a one-GPU box).
 """
 import os
 import sys
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 import torch
@@ -36,16 +48,51 @@ from .host import NbnxnHost, PairList
 
 
 @dataclass
+class Message:
+    """One halo message per step and direction: my home atoms `send_sel` go to `send_to`, `n_recv` atoms arrive from
+    `recv_from` (its message of the same offset) and form one grid zone here."""
+    offset: tuple              # (dx, dy, dz): where the rank I import from sits relative to me
+    send_to: int
+    recv_from: int
+    n_send: int
+    n_recv: int
+    shift: np.ndarray          # [3], added to the coordinates on the way (periodic boundaries crossed)
+    shift_index: int           # the shift force the returned forces count towards (-1: none)
+
+
+def shift_index(tx, ty, tz):
+    """XYZ2IS (types/ishift.h:45-55)"""
+    return 5 * (3 * (tz + 1) + ty + 1) + tx + 2
+
+
+def rank_of(idx, grid):
+    return (int(idx[2]) * grid[1] + int(idx[1])) * grid[0] + int(idx[0])
+
+
+def coords_of(rank, grid):
+    return (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+
+
+def forward_offsets(decomp):
+    """The half shell over the cut dimensions: offsets (dx, dy, dz) with (dz, dy, dx) > (0, 0, 0)."""
+    r = [(-1, 0, 1) if d else (0,) for d in decomp]
+    return [(dx, dy, dz) for dz in r[2] for dy in r[1] for dx in r[0] if (dz, dy, dx) > (0, 0, 0)]
+
+
+@dataclass
 class Domain:
     rank: int
     world: int
+    grid: tuple                # ranks along x, y, z
+    decomp: tuple              # which dimensions are cut (a single rank cuts the ones it is its own neighbour in)
     box: np.ndarray            # global box (its diagonal)
     box_search: np.ndarray     # the box as the search takes it: [3], or the [3, 3] matrix of a cell skewed in xy
-    lz: float                  # slab thickness
+    lo: np.ndarray             # corners of the home brick
+    hi: np.ndarray
     nhome: int                 # home atoms (caller order: home first, halo after)
     nhalo: int
     home_ids: np.ndarray       # global atom ids of the home atoms
-    halo_ids: np.ndarray       # global atom ids of the imported atoms, in arrival order
+    halo_ids: np.ndarray       # global atom ids of the imported atoms, in arrival order (message by message)
     host: NbnxnHost
     xq: np.ndarray             # [npad, 4] grid order, home grid first
     type: np.ndarray           # [npad]
@@ -56,9 +103,9 @@ class Domain:
     pl_nonlocal: PairList
     npad: int
     npad_local: int
-    send_slots: np.ndarray     # grid slots of the home atoms the lower neighbour imports
-    send_zshift: float         # added to their z on the way (periodic wrap at the bottom rank)
-    halo_slots: np.ndarray     # grid slots the imported atoms occupy here
+    msgs: list                 # [Message], in the order of forward_offsets(decomp)
+    send_slots: np.ndarray     # grid slots of the home atoms that go out, message by message
+    halo_slots: np.ndarray     # grid slots the imported atoms occupy here, message by message
     # what the device search needs to redo the gridding and both lists (nbnxn_hip_put_on_grid_zones)
     zones: list = None         # [(corner0, corner1, a0, n)], home zone first
     x_all: np.ndarray = None   # caller order: home atoms, then the imported ones
@@ -74,12 +121,8 @@ class Domain:
         return (self.pl_local.nci_tot + self.pl_nonlocal.nci_tot) * 64
 
     @property
-    def up(self):
-        return (self.rank + 1) % self.world
-
-    @property
-    def down(self):
-        return (self.rank - 1) % self.world
+    def pbc_shift_dim(self):
+        return tuple(0 if d else 1 for d in self.decomp)
 
 
 def _staged(t):
@@ -116,60 +159,109 @@ def _exchange(send, dst, recv, src):
     dist.all_to_all_single(recv, send, output_split_sizes=outs, input_split_sizes=ins)
 
 
-def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
-    """Cuts rank `rank`'s slab out of the global system `glob` (every rank holds the synthetic
+def _exchange_split(send, in_splits, recv, out_splits):
+    """One all_to_all_single with per-rank row counts: all messages of a step and direction at once."""
+    if _staged(send) or _staged(recv):
+        hs = send.cpu()
+        hr = torch.empty(recv.shape, dtype=recv.dtype)
+        _exchange_split(hs, in_splits, hr, out_splits)
+        recv.copy_(hr)
+        return
+    dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
+def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,)):
+    """Cuts rank `rank`'s brick out of the global system `glob` (every rank holds the synthetic
     global topology; coordinates of imported atoms still arrive by message, as they would in a
-    run), grids home and halo zones, and builds both lists."""
+    run), grids home and halo zones, and builds both lists.  grid = ranks along (x, y, z), default z slabs."""
     if world < 1:
         raise ValueError("domain decomposition needs at least one rank")
-    # a triclinic cell may be decomposed along z as long as box[ZZ] lies along z (the halo shift is then the plain
-    # z translation these messages apply); box[YY][XX] may be skewed, the search handles it through its x/y shifts
+    grid = (1, 1, world) if grid is None else tuple(int(v) for v in grid)
+    if len(grid) != 3 or min(grid) < 1 or grid[0] * grid[1] * grid[2] != world:
+        raise ValueError(f"a grid of {grid} ranks does not hold {world} ranks")
+    decomp = tuple(grid[d] > 1 or (world == 1 and d in self_dims) for d in range(3))
+    # A triclinic cell may be cut along a dimension whose box vector lies along its axis and into which no other box
+    # vector reaches (the halo shift is then a plain translation along that axis): along z, box[YY][XX] may be skewed,
+    # the search handles it through its x/y shifts.
     box_search = np.asarray(glob.box, dtype=np.float32)
     if box_search.shape == (3, 3):
-        if box_search[2, 0] != 0 or box_search[2, 1] != 0:
-            raise ValueError("slab decomposition along z needs box[ZZ] along z")
+        m = box_search
+        bad = {2: m[2, 0] != 0 or m[2, 1] != 0, 1: m[1, 0] != 0 or m[2, 1] != 0, 0: m[1, 0] != 0 or m[2, 0] != 0}
+        for d in range(3):
+            if decomp[d] and bad[d]:
+                raise ValueError(f"a decomposition along {'xyz'[d]} needs box[{'XYZ'[d]}{'XYZ'[d]}] along its axis and no other box vector reaching into it")
         box = np.ascontiguousarray(np.diag(box_search))
     else:
         box = box_search
-    lz = float(box[2]) / world
-    # one rank is its own neighbour: periodic in z through a halo of its own atoms, which needs room for both
-    if lz <= ip.rlist * (2 if world == 1 else 1):
-        raise ValueError(f"slab thickness {lz:.3f} nm must exceed {'2 x ' if world == 1 else ''}rlist {ip.rlist:.3f} nm")
-    z = glob.x[:, 2].astype(np.float64)
-    owner = np.clip(np.floor(z / lz).astype(np.int64), 0, world - 1)
+    ext = np.array([float(box[d]) / grid[d] for d in range(3)])
+    for d in range(3):
+        # one rank is its own neighbour: periodic through a halo of its own atoms, which needs room for both
+        if decomp[d] and ext[d] <= ip.rlist * (2 if grid[d] == 1 else 1):
+            raise ValueError(f"brick thickness {ext[d]:.3f} nm along {'xyz'[d]} must exceed {'2 x ' if grid[d] == 1 else ''}rlist {ip.rlist:.3f} nm")
+    me = coords_of(rank, grid)
+    cell3 = [np.clip(np.floor(glob.x[:, d].astype(np.float64) / ext[d]).astype(np.int64), 0, grid[d] - 1) for d in range(3)]
+    owner = (cell3[2] * grid[1] + cell3[1]) * grid[0] + cell3[0]
     home_ids = np.nonzero(owner == rank)[0]
     nhome = len(home_ids)
     x_home = glob.x[home_ids]
+    lo = np.array([me[d] * ext[d] for d in range(3)])
+    hi = lo + ext
+    rl = np.float32(ip.rlist)
 
-    # what the lower neighbour imports from me: my atoms within rlist of my lower face
-    zrel = x_home[:, 2] - np.float32(rank * lz)
-    down_sel = np.nonzero(zrel < ip.rlist)[0]
-    send_zshift = float(box[2]) if rank == 0 else 0.0
-    up, down = (rank + 1) % world, (rank - 1) % world
+    msgs, sels, halo_id_parts, halo_x_parts = [], [], [], []
+    for o in forward_offsets(decomp):
+        # what the rank at me - o imports from me: my atoms within rlist of the face / edge / corner we share
+        sel = np.ones(nhome, dtype=bool)
+        t = [0, 0, 0]
+        for d in range(3):
+            if o[d] == 1:
+                sel &= (x_home[:, d] - np.float32(lo[d])) < rl
+                t[d] = 1 if me[d] == 0 else 0                    # it sits at the top of the box: + box
+            elif o[d] == -1:
+                sel &= (np.float32(hi[d]) - x_home[:, d]) <= rl
+                t[d] = -1 if me[d] == grid[d] - 1 else 0         # it sits at the bottom of the box: - box
+        sel = np.nonzero(sel)[0]
+        shift = np.array([t[d] * float(box[d]) for d in range(3)], dtype=np.float32)
+        send_to = rank_of([(me[d] - o[d]) % grid[d] for d in range(3)], grid)
+        recv_from = rank_of([(me[d] + o[d]) % grid[d] for d in range(3)], grid)
+        n_send = torch.tensor([len(sel)], dtype=torch.int64, device=device)
+        n_recv = torch.zeros(1, dtype=torch.int64, device=device)
+        _exchange(n_send, send_to, n_recv, recv_from)
+        nr = int(n_recv.item())
+        ids_send = torch.from_numpy(home_ids[sel].astype(np.int64)).to(device)
+        x_send = torch.from_numpy(x_home[sel] + shift).to(device)
+        ids_recv = torch.zeros(nr, dtype=torch.int64, device=device)
+        x_recv = torch.zeros((nr, 3), dtype=torch.float32, device=device)
+        _exchange(ids_send, send_to, ids_recv, recv_from)
+        _exchange(x_send, send_to, x_recv, recv_from)
+        msgs.append(Message(offset=o, send_to=send_to, recv_from=recv_from, n_send=len(sel), n_recv=nr, shift=shift,
+                            shift_index=shift_index(*t) if any(t) else -1))
+        sels.append(sel)
+        halo_id_parts.append(ids_recv.cpu().numpy())
+        halo_x_parts.append(x_recv.cpu().numpy())
+    halo_ids = np.concatenate(halo_id_parts) if halo_id_parts else np.zeros(0, np.int64)
+    x_halo = np.concatenate(halo_x_parts) if halo_x_parts else np.zeros((0, 3), np.float32)
+    nhalo = len(halo_ids)
 
-    n_send = torch.tensor([len(down_sel)], dtype=torch.int64, device=device)
-    n_recv = torch.zeros(1, dtype=torch.int64, device=device)
-    _exchange(n_send, down, n_recv, up)
-    nhalo = int(n_recv.item())
-    ids_send = torch.from_numpy(home_ids[down_sel].astype(np.int64)).to(device)
-    xs = x_home[down_sel].copy()
-    xs[:, 2] += np.float32(send_zshift)
-    x_send = torch.from_numpy(xs).to(device)
-    ids_recv = torch.zeros(nhalo, dtype=torch.int64, device=device)
-    x_recv = torch.zeros((nhalo, 3), dtype=torch.float32, device=device)
-    _exchange(ids_send, down, ids_recv, up)
-    _exchange(x_send, down, x_recv, up)
-    halo_ids = ids_recv.cpu().numpy()
-    x_halo = x_recv.cpu().numpy()
-
-    # grids: zone 0 = home slab, zone 1 = the rlist-thick layer above it
-    host = NbnxnHost(box_search, pbc_shift_dim=(1, 1, 0))
-    z0 = rank * lz
-    zones = [((0.0, 0.0, z0), (float(box[0]), float(box[1]), z0 + lz), 0, nhome)]
+    # grids: zone 0 = the home brick, then one zone per message that brought atoms: the rlist-thick layer beyond the
+    # face (edge, corner) it came across
+    pbc_shift_dim = tuple(0 if d else 1 for d in decomp)
+    host = NbnxnHost(box_search, pbc_shift_dim=pbc_shift_dim)
+    c0 = [float(lo[d]) if decomp[d] else 0.0 for d in range(3)]
+    c1 = [float(hi[d]) if decomp[d] else float(box[d]) for d in range(3)]
+    zones = [(tuple(c0), tuple(c1), 0, nhome)]
     host.put_on_grid(0, zones[0][0], zones[0][1], 0, x_home)
-    if nhalo > 0:
-        zones.append(((0.0, 0.0, z0 + lz), (float(box[0]), float(box[1]), z0 + lz + ip.rlist), nhome, nhalo))
-        host.put_on_grid(1, zones[1][0], zones[1][1], nhome, x_halo)
+    a0 = nhome
+    for m, xh in zip(msgs, halo_x_parts):
+        if m.n_recv == 0:
+            continue
+        z0 = [c1[d] if m.offset[d] == 1 else (c0[d] - float(rl) if m.offset[d] == -1 else c0[d]) for d in range(3)]
+        z1 = [c1[d] + float(rl) if m.offset[d] == 1 else (c0[d] if m.offset[d] == -1 else c1[d]) for d in range(3)]
+        zones.append((tuple(z0), tuple(z1), a0, m.n_recv))
+        host.put_on_grid(len(zones) - 1, zones[-1][0], zones[-1][1], a0, xh)
+        a0 += m.n_recv
+    if len(zones) > abi.MAX_ZONES:
+        raise ValueError(f"{len(zones)} grid zones, the search takes {abi.MAX_ZONES}")
     ids_all = np.concatenate([home_ids, halo_ids])
     x_all = np.concatenate([x_home, x_halo]).astype(np.float32)
     ntype = glob.ntype + 1
@@ -177,22 +269,21 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     host.copy_x_to_xq(x_all, xq)
 
     # topology exclusions in local numbering; partners that are not on this rank drop out.  A partner maps to every
-    # copy of it that this rank holds: its home atom and / or its halo image (both only when one rank is its own
-    # neighbour; an exclusion between copies that are out of range of each other is never looked at).
+    # copy of it that this rank holds: its home atom and its halo images (several when a rank is the neighbour on more
+    # than one side; an exclusion between copies that are out of range of each other is never looked at).
     nloc = len(ids_all)
-    g2l_home = np.full(glob.natoms, -1, dtype=np.int64)
-    g2l_home[home_ids] = np.arange(nhome)
-    g2l_halo = np.full(glob.natoms, -1, dtype=np.int64)
-    g2l_halo[halo_ids] = nhome + np.arange(nhalo)
+    by_id = np.argsort(ids_all, kind="stable")
+    ids_sorted = ids_all[by_id]
     cnt = (glob.excl_index[1:] - glob.excl_index[:-1])[ids_all]
     starts = glob.excl_index[:-1][ids_all]
     flat = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
     row = np.repeat(np.arange(nloc), cnt)
     gp = glob.excl_a[flat]
-    rows = np.concatenate([row, row])
-    partners = np.concatenate([g2l_home[gp], g2l_halo[gp]])
-    keep = partners >= 0
-    rows, partners = rows[keep], partners[keep]
+    first = np.searchsorted(ids_sorted, gp, side="left")
+    ncopy = np.searchsorted(ids_sorted, gp, side="right") - first
+    rows = np.repeat(row, ncopy)
+    within = np.arange(int(ncopy.sum())) - np.repeat(np.concatenate([[0], np.cumsum(ncopy)[:-1]]), ncopy)
+    partners = by_id[np.repeat(first, ncopy) + within]
     order = np.lexsort((partners, rows))
     rows, partners = rows[order], partners[order]
     excl_index = np.zeros(nloc + 1, dtype=np.int32)
@@ -203,99 +294,133 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0):
     pl_local = host.make_pairlist(abi.LOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
     pl_nonlocal = host.make_pairlist(abi.NONLOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
     cell = host.cell_index()
-    return Domain(rank=rank, world=world, box=box, box_search=box_search, lz=lz, nhome=nhome, nhalo=nhalo, home_ids=home_ids,
-                  halo_ids=halo_ids, host=host, xq=xq, type=typ, ntype=ntype, nbfp=glob.nbfp(),
+    send_slots = np.concatenate([cell[sel] for sel in sels]).astype(np.int64) if sels else np.zeros(0, np.int64)
+    return Domain(rank=rank, world=world, grid=grid, decomp=decomp, box=box, box_search=box_search, lo=lo, hi=hi, nhome=nhome, nhalo=nhalo,
+                  home_ids=home_ids, halo_ids=halo_ids, host=host, xq=xq, type=typ, ntype=ntype, nbfp=glob.nbfp(),
                   shift_vec=host.shift_vec(), pl_local=pl_local, pl_nonlocal=pl_nonlocal,
-                  npad=len(xq), npad_local=host.natoms_padded_local,
-                  send_slots=cell[down_sel].astype(np.int64), send_zshift=send_zshift,
-                  halo_slots=cell[nhome:nhome + nhalo].astype(np.int64),
+                  npad=len(xq), npad_local=host.natoms_padded_local, msgs=msgs,
+                  send_slots=send_slots, halo_slots=cell[nhome:nhome + nhalo].astype(np.int64),
                   zones=zones, x_all=x_all, type_all=glob.type[ids_all].astype(np.int32), q_all=glob.q[ids_all].astype(np.float32),
                   excl_index=excl_index, excl_a=excl_a, rlist=float(ip.rlist), min_ci_balanced=int(min_ci_balanced))
 
 
+class _Layout:
+    """Row orders of the per-step buffers.  The slot lists of a Domain are message by message; one all_to_all_single
+    wants the rows it sends ordered by destination rank and delivers the rows it receives ordered by source rank.
+    Messages between the same two ranks keep their message order on both sides (both count them by the same offset)."""
+
+    def __init__(self, dom):
+        ms = dom.msgs
+        s_start = np.concatenate([[0], np.cumsum([m.n_send for m in ms])]).astype(np.int64)
+        r_start = np.concatenate([[0], np.cumsum([m.n_recv for m in ms])]).astype(np.int64)
+        self.out_order = sorted(range(len(ms)), key=lambda k: (ms[k].send_to, k))      # coordinates out / forces in
+        self.in_order = sorted(range(len(ms)), key=lambda k: (ms[k].recv_from, k))     # coordinates in / forces out
+        cat = lambda parts: np.concatenate(parts).astype(np.int64) if parts else np.zeros(0, np.int64)
+        self.send_slots = cat([dom.send_slots[s_start[k]:s_start[k + 1]] for k in self.out_order])
+        self.halo_slots = cat([dom.halo_slots[r_start[k]:r_start[k + 1]] for k in self.in_order])
+        self.send_rows = np.zeros(dom.world, dtype=np.int64)     # rows per rank: coordinates out = forces in
+        self.recv_rows = np.zeros(dom.world, dtype=np.int64)     # coordinates in = forces out
+        self.out_seg, off = [], 0                                 # (message, first row, rows) in the send-side buffers
+        for k in self.out_order:
+            self.send_rows[ms[k].send_to] += ms[k].n_send
+            self.out_seg.append((k, off, ms[k].n_send))
+            off += ms[k].n_send
+        for k in self.in_order:
+            self.recv_rows[ms[k].recv_from] += ms[k].n_recv
+        self.send_rows, self.recv_rows = [int(v) for v in self.send_rows], [int(v) for v in self.recv_rows]
+        self.n_send, self.n_recv = int(s_start[-1]), int(r_start[-1])
+
+
 class HaloExchange:
     """The per-step messages, on tensors that alias the engine's coordinate and force arrays:
-    xq_t [npad, 4] and f_t [npad, 3] (grid order)."""
+    xq_t [npad, 4] and f_t [npad, 3] (grid order).  All messages of a direction go out in one all_to_all_single."""
 
     def __init__(self, dom, xq_t, f_t):
         dev = xq_t.device
         self.dom, self.xq_t, self.f_t = dom, xq_t, f_t
-        self.send_slots = torch.from_numpy(dom.send_slots).to(dev)
-        self.halo_slots = torch.from_numpy(dom.halo_slots).to(dev)
-        self.zshift = torch.tensor([0.0, 0.0, dom.send_zshift, 0.0], dtype=torch.float32, device=dev)
-        self.x_out = torch.zeros((len(dom.send_slots), 4), dtype=torch.float32, device=dev)
-        self.x_in = torch.zeros((dom.nhalo, 4), dtype=torch.float32, device=dev)
-        self.f_out = torch.zeros((dom.nhalo, 3), dtype=f_t.dtype, device=dev)
-        self.f_in = torch.zeros((len(dom.send_slots), 3), dtype=f_t.dtype, device=dev)
-        # forces that come back across the periodic wrap count towards the shift force of
-        # (0, 0, +1), as dd_move_f does for shifted pulses (mdlib/domdec.c:1046-1068): the
-        # virial needs  box_z (x) sum of those forces
-        self.wrap_shift = 5 * (3 * (1 + 1) + 0 + 1) + 0 + 2 if dom.send_zshift != 0.0 else -1
-        self.fshift_wrap = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.lay = lay = _Layout(dom)
+        self.send_slots = torch.from_numpy(lay.send_slots).to(dev)
+        self.halo_slots = torch.from_numpy(lay.halo_slots).to(dev)
+        shift_rows = np.zeros((lay.n_send, 4), dtype=np.float32)
+        for k, off, n in lay.out_seg:
+            shift_rows[off:off + n, :3] = dom.msgs[k].shift
+        self.shift_rows = torch.from_numpy(shift_rows).to(dev)
+        self.x_out = torch.zeros((lay.n_send, 4), dtype=torch.float32, device=dev)
+        self.x_in = torch.zeros((lay.n_recv, 4), dtype=torch.float32, device=dev)
+        self.f_out = torch.zeros((lay.n_recv, 3), dtype=f_t.dtype, device=dev)
+        self.f_in = torch.zeros((lay.n_send, 3), dtype=f_t.dtype, device=dev)
+        # forces that come back across a periodic boundary count towards the shift force of that crossing, as
+        # dd_move_f does for shifted pulses (mdlib/domdec.c:837-851): the virial needs  shift vector (x) their sum
+        self.wrap_seg = [(dom.msgs[k].shift_index, off, n) for k, off, n in lay.out_seg if dom.msgs[k].shift_index >= 0]
+        self.fshift_wrap = torch.zeros((abi.SHIFTS, 3), dtype=torch.float64, device=dev)
 
     def send_x(self):
-        """home {x,y,z,q} rows the lower neighbour imports go down; mine arrive from above."""
+        """home {x,y,z,q} rows go to the ranks that import them; mine arrive from the forward neighbours."""
         torch.index_select(self.xq_t, 0, self.send_slots, out=self.x_out)
-        if self.wrap_shift >= 0:
-            self.x_out += self.zshift
-        _exchange(self.x_out, self.dom.down, self.x_in, self.dom.up)
+        self.x_out += self.shift_rows
+        _exchange_split(self.x_out, self.lay.send_rows, self.x_in, self.lay.recv_rows)
         self.xq_t.index_copy_(0, self.halo_slots, self.x_in)
 
     def return_f(self):
-        """forces on imported atoms go back up to their owner, who adds them."""
+        """forces on imported atoms go back to their owner, who adds them."""
         torch.index_select(self.f_t, 0, self.halo_slots, out=self.f_out)
-        _exchange(self.f_out, self.dom.up, self.f_in, self.dom.down)
+        _exchange_split(self.f_out, self.lay.recv_rows, self.f_in, self.lay.send_rows)
         self.f_t.index_add_(0, self.send_slots, self.f_in)
-        if self.wrap_shift >= 0:
-            self.fshift_wrap = self.f_in.to(torch.float64).sum(0)
+        self.fshift_wrap.zero_()
+        for si, off, n in self.wrap_seg:
+            self.fshift_wrap[si] += self.f_in[off:off + n].to(torch.float64).sum(0)
 
     def add_wrap_fshift(self, out_t):
         """the same term, added straight into accumulation slot 0 of the engine's output buffer"""
-        if self.wrap_shift >= 0:
-            out_t[2 + 3 * self.wrap_shift:5 + 3 * self.wrap_shift] += self.fshift_wrap.to(out_t.dtype)
+        if self.wrap_seg:
+            out_t[2:2 + 3 * abi.SHIFTS] += self.fshift_wrap.reshape(-1).to(out_t.dtype)
 
 
 class DeviceHalo:
     """The same messages with the buffers packed and unpacked by the HIP module's halo kernels
-    (nbnxn_hip_halo_*) on its non-local stream: four kernel launches through the C ABI per step instead
-    of nine torch operations, and the shift-force term of the periodic wrap is added by the kernel
-    that adds the returned forces.  The exchange itself goes out on torch's CURRENT stream, which the
+    (nbnxn_hip_halo_*) on its non-local stream, and the shift-force term of a periodic crossing added by the
+    kernel that adds the returned forces (one pack and one unpack launch per message on the sending side, one
+    launch for all on the importing side).  The exchange itself goes out on torch's CURRENT stream, which the
     caller sets to the module's non-local stream (SlabRun.step)."""
 
     def __init__(self, nb, dom, dev):
         import ctypes as C
         self.nb, self.dom = nb, dom
-        self.send_slots = torch.from_numpy(dom.send_slots.astype(np.int32)).to(dev)
-        self.halo_slots = torch.from_numpy(dom.halo_slots.astype(np.int32)).to(dev)
-        self.n_send, self.n_halo = len(dom.send_slots), int(dom.nhalo)
+        self.lay = lay = _Layout(dom)
+        self.send_slots = torch.from_numpy(lay.send_slots.astype(np.int32)).to(dev)
+        self.halo_slots = torch.from_numpy(lay.halo_slots.astype(np.int32)).to(dev)
+        self.n_send, self.n_halo = lay.n_send, lay.n_recv
         self.x_out = torch.zeros((self.n_send, 4), dtype=torch.float32, device=dev)
         self.x_in = torch.zeros((self.n_halo, 4), dtype=torch.float32, device=dev)
         self.f_out = torch.zeros((self.n_halo, 3), dtype=torch.float32, device=dev)
         self.f_in = torch.zeros((self.n_send, 3), dtype=torch.float32, device=dev)
-        wrap = dom.send_zshift != 0.0
-        self.shift = (C.c_float * 3)(0.0, 0.0, float(dom.send_zshift)) if wrap else None
-        self.wrap_shift = 5 * (3 * (1 + 1) + 0 + 1) + 0 + 2 if wrap else -1     # shift (0, 0, +1), as in HaloExchange
         self._p = [t.data_ptr() for t in (self.send_slots, self.halo_slots, self.x_out, self.x_in, self.f_out, self.f_in)]
+        # (rows, first row, shift or None, shift index) of every message with something to send
+        self.seg = [(n, off, (C.c_float * 3)(*[float(v) for v in dom.msgs[k].shift]) if dom.msgs[k].shift_index >= 0 else None,
+                     dom.msgs[k].shift_index) for k, off, n in lay.out_seg if n > 0]
 
     def send_x(self):
         p = self._p
-        self.nb.halo_pack_x(p[0], self.n_send, self.shift, p[2], abi.NONLOCAL)
-        _exchange(self.x_out, self.dom.down, self.x_in, self.dom.up)
+        for n, off, shift, _ in self.seg:
+            self.nb.halo_pack_x(p[0] + 4 * off, n, shift, p[2] + 16 * off, abi.NONLOCAL)
+        _exchange_split(self.x_out, self.lay.send_rows, self.x_in, self.lay.recv_rows)
         self.nb.halo_unpack_x(p[1], self.n_halo, p[3], abi.NONLOCAL)
 
     def return_f(self):
         p = self._p
         self.nb.halo_pack_f(p[1], self.n_halo, p[4], abi.NONLOCAL)
-        _exchange(self.f_out, self.dom.up, self.f_in, self.dom.down)
-        self.nb.halo_unpack_f(p[0], self.n_send, p[5], self.wrap_shift, abi.NONLOCAL)
+        _exchange_split(self.f_out, self.lay.recv_rows, self.f_in, self.lay.send_rows)
+        for n, off, _, si in self.seg:
+            self.nb.halo_unpack_f(p[0] + 4 * off, n, p[5] + 12 * off, si, abi.NONLOCAL)
 
 
 class RcclHalo:
-    """The same messages issued by the HIP module itself (nbnxn_hip_dd_*): pack kernel, one grouped
-    ncclSend / ncclRecv between devices, unpack kernel, all on the module's non-local stream from ONE call
-    through the C ABI; the slot reduction is the module's ncclAllReduce.  No torch stream is involved, so the
-    step needs no set_stream and no hand-over between torch's collective stream and the module's.  The
-    communicator is the module's own: rank 0 makes the RCCL id, torch.distributed only carries its 128 bytes."""
+    """The same messages issued by the HIP module itself (nbnxn_hip_dd_*): one pack kernel, one grouped set of
+    ncclSend / ncclRecv between devices, one unpack kernel, all on the module's non-local stream from ONE call
+    through the C ABI, however many messages there are; the slot reduction is the module's ncclAllReduce.  No torch
+    stream is involved, so the step needs no set_stream and no hand-over between torch's collective stream and the
+    module's.  The communicator is the module's own: rank 0 makes the RCCL id, torch.distributed only carries its
+    128 bytes."""
 
     def __init__(self, nb, dom, dev):
         self.nb, self.dom = nb, dom
@@ -305,11 +430,9 @@ class RcclHalo:
             idt.copy_(torch.frombuffer(bytearray(nb.dd_get_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         nb.dd_init(bytes(idt.cpu().numpy().tobytes()), dom.rank, dom.world)
-        wrap = dom.send_zshift != 0.0
-        self.wrap_shift = 5 * (3 * (1 + 1) + 0 + 1) + 0 + 2 if wrap else -1     # shift (0, 0, +1), as in HaloExchange
         self.halo_slots = torch.from_numpy(dom.halo_slots.astype(np.int64)).to(dev)
-        nb.dd_set_pulse(dom.down, dom.up, dom.send_slots, dom.halo_slots, (0.0, 0.0, float(dom.send_zshift)) if wrap else None,
-                        self.wrap_shift)
+        nb.dd_set_messages([(m.send_to, m.recv_from, m.n_send, m.n_recv, m.shift_index, m.shift) for m in dom.msgs],
+                           dom.send_slots, dom.halo_slots)
 
     def send_x(self):
         self.nb.dd_move_x()
@@ -336,8 +459,8 @@ def fold_slots(out_t):
 def fold_and_reduce(out_t, halo=None):
     """{e_lj, e_el, fshift[45][3]} summed over the accumulation slots in double, then over ranks."""
     e = out_t.view(-1, abi.OUT_STRIDE).to(torch.float64).sum(0)
-    if halo is not None and halo.wrap_shift >= 0:
-        e[2 + 3 * halo.wrap_shift:5 + 3 * halo.wrap_shift] += halo.fshift_wrap
+    if halo is not None and halo.wrap_seg:
+        e[2:2 + 3 * abi.SHIFTS] += halo.fshift_wrap.reshape(-1)
     if _staged(e):
         h = e.cpu()
         dist.all_reduce(h)
@@ -356,11 +479,11 @@ class _DevArray:
 
 
 class SlabRun:
-    """The multi-GPU workload of bench.py: water_box(tx, ty, tz * world) (weak scaling) or water_box(tx, ty, tz)
-    (strong scaling, BASELINE configs[3]) cut into `world` z slabs of equal thickness."""
+    """The multi-GPU workload of bench.py: water_box(tx * nx, ty * ny, tz * nz) (weak scaling) or water_box(tx, ty, tz)
+    (strong scaling, BASELINE configs[3]) cut into grid = (nx, ny, nz) bricks of equal size, default `world` z slabs."""
 
     def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None, device_search=True,
-                 device_halo=True, rccl_direct=False, strong=False):
+                 device_halo=True, rccl_direct=False, strong=False, grid=None, self_dims=(2,)):
         """device_halo: halo buffers packed by the module's kernels (else torch indexing operations), messages
         through torch.distributed.  rccl_direct: everything, messages included, issued by the module on its own
         RCCL communicator (needs one GPU per rank)."""
@@ -368,16 +491,17 @@ class SlabRun:
         self.flags = flags
         self.dev = torch.device("cuda", local_rank)
         # weak scaling: `tiles` per rank, stacked along z; strong scaling: `tiles` is the whole box, cut into `world` slabs
-        glob = sysmod.water_box(tiles[0], tiles[1], tiles[2] * (1 if strong else world), model=model)
+        grid = (1, 1, world) if grid is None else tuple(int(v) for v in grid)
+        glob = sysmod.water_box(*[tiles[d] * (1 if strong else grid[d]) for d in range(3)], model=model)
         self.natoms_global = glob.natoms
         self.nb = nb = gpu.NbnxnHip(local_rank, local_and_nonlocal=True)
         mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced
-        self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb)
+        self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims)
         nb.init_const(ip, dom.ntype, dom.nbfp)
         if device_search:
             # grids and both lists made on the device; the host-side builder's results, which the
             # halo bookkeeping above came from, double as the check that both see the same grid
-            npad = nb.put_on_grid_zones(dom.box_search, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=(1, 1, 0))
+            npad = nb.put_on_grid_zones(dom.box_search, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=dom.pbc_shift_dim)
             assert npad == dom.npad
             nb.make_pairlist(dom.rlist, dom.excl_index, dom.excl_a, dom.min_ci_balanced, iloc=abi.LOCAL)
             if len(dom.zones) > 1:
@@ -443,7 +567,8 @@ class SlabRun:
 
     def describe(self):
         d = self.dom
-        return {"atoms_rank0": d.nhome, "halo_atoms_rank0": d.nhalo, "nsci_local": d.pl_local.nsci,
+        return {"dd_grid": list(d.grid), "halo_messages": len(d.msgs), "halo_zones": len(d.zones) - 1,
+                "atoms_rank0": d.nhome, "halo_atoms_rank0": d.nhalo, "nsci_local": d.pl_local.nsci,
                 "nsci_nonlocal": d.pl_nonlocal.nsci, "cluster_pairs_rank0": d.pl_local.nci_tot + d.pl_nonlocal.nci_tot}
 
     def step(self, ev=None):

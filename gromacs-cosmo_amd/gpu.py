@@ -121,6 +121,7 @@ def load():
     lib.nbnxn_hip_dd_get_unique_id.argtypes = [C.c_char_p]
     lib.nbnxn_hip_dd_init.argtypes = [vp, C.c_char_p, ci, ci]
     lib.nbnxn_hip_dd_set_pulse.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci]
+    lib.nbnxn_hip_dd_set_messages.argtypes = [vp, ci, vp, vp, vp]
     lib.nbnxn_hip_dd_move_x.argtypes = [vp]
     lib.nbnxn_hip_dd_move_f.argtypes = [vp]
     lib.nbnxn_hip_dd_sum_outputs.argtypes = [vp, ci]
@@ -420,6 +421,18 @@ class NbnxnHip:
         rs = np.ascontiguousarray(recv_slots, dtype=np.int32)
         sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
         self._chk(self.lib.nbnxn_hip_dd_set_pulse(self.h, send_to, recv_from, abi.ptr(ss), len(ss), abi.ptr(rs), len(rs), abi.ptr(sh), shift_index))
+
+    def dd_set_messages(self, msgs, send_slots, recv_slots):
+        """msgs: list of (send_to, recv_from, n_send, n_recv, shift_index, shift[3]); the slot arrays hold the
+        slots of all messages back to back, in message order (nbnxn_hip_dd_set_messages)."""
+        ms = (abi.DdMessage * len(msgs))()
+        for k, (to, frm, ns, nr, si, sh) in enumerate(msgs):
+            ms[k].send_to, ms[k].recv_from, ms[k].n_send, ms[k].n_recv, ms[k].shift_index = int(to), int(frm), int(ns), int(nr), int(si)
+            ms[k].shift[:] = [float(v) for v in sh]
+        ss = np.ascontiguousarray(send_slots, dtype=np.int32)
+        rs = np.ascontiguousarray(recv_slots, dtype=np.int32)
+        assert len(ss) == sum(m[2] for m in msgs) and len(rs) == sum(m[3] for m in msgs)
+        self._chk(self.lib.nbnxn_hip_dd_set_messages(self.h, len(msgs), ms, abi.ptr(ss), abi.ptr(rs)))
 
     def dd_move_x(self):
         self._chk(self.lib.nbnxn_hip_dd_move_x(self.h))

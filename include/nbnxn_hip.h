@@ -33,6 +33,8 @@ extern "C" {
 #define NBX_NCL_PER_SUPERCL      8   /* clusters per super-cluster (2x2x2)               */
 #define NBX_JGROUP_SIZE          4   /* j-clusters per cj4 entry                         */
 #define NBX_SHIFTS              45   /* SHIFTS                                           */
+#define NBX_MAX_ZONES           14   /* grid zones of one domain: home + 13 halo zones (half shell in 3-D); the reference's eighth shell has 8 (domdec.c:433-449) */
+#define NBX_DD_MAX_MESSAGES     13   /* halo messages of one domain per step and direction (one per halo zone)                        */
 #define NBX_CENTRAL             22   /* CENTRAL                                          */
 #define NBX_AVOID_SING_R2_INC   1.0e-12f
 
@@ -596,8 +598,11 @@ int nbnxn_hip_reserved_cus(nbnxn_hip_ptr_t nb);
  * domdec_network.c:114) becomes pack kernel -> one grouped ncclSend / ncclRecv between devices ->
  * unpack kernel on the non-local stream; energies and shift forces are summed over ranks by one
  * ncclAllReduce of the accumulation slots (the reference sums them on the host in global_stat).
- * One pulse along one dimension (the slab decomposition of gromacs-cosmo_amd/dd.py).  RCCL is bound
- * at run time: the copy the process already holds (librccl.so.1), else the system's.
+ * One pulse along one dimension (nbnxn_hip_dd_set_pulse, the slab decomposition of gromacs-cosmo_amd/dd.py), or up to
+ * NBX_DD_MAX_MESSAGES messages with direct peers (nbnxn_hip_dd_set_messages: a decomposition in two or three dimensions
+ * whose halo zones each come straight from the rank that owns them, no forwarding through intermediate ranks as in
+ * the staged pulses of domdec.c:667-758 -- on a node whose GPUs are all linked to each other every neighbour is
+ * one hop away).  RCCL is bound at run time: the copy the process already holds (librccl.so.1), else the system's.
  * ---------------------------------------------------------------------------------- */
 #define NBX_DD_UNIQUE_ID_BYTES 128
 /* ncclGetUniqueId: one rank makes the id, the host's launcher hands it to the others (mdrun:
@@ -611,7 +616,23 @@ int nbnxn_hip_dd_init(nbnxn_hip_ptr_t nb, const char *id128, int rank, int nrank
  * force shift_index as well (-1: not).  Host arrays; copied. */
 int nbnxn_hip_dd_set_pulse(nbnxn_hip_ptr_t nb, int send_to, int recv_from, const int *send_slots, int n_send,
                            const int *recv_slots, int n_recv, const float *shift, int shift_index);
-/* dd_move_x / dd_move_f for that pulse, asynchronous on the non-local stream; every rank calls them.
+/* The general form: nmsg messages (1..NBX_DD_MAX_MESSAGES) per step and direction.  Message k carries the coordinates
+ * of n_send grid slots to rank send_to, each plus shift (the box vectors of the periodic boundaries the message
+ * crosses; zeros = none), and fills n_recv grid slots with what rank recv_from sends as ITS message k; forces travel
+ * the reverse way, and those that arrive for message k add to the shift force shift_index as well (-1: not), the rule
+ * of dd_move_f for pulses across a periodic boundary (domdec.c:837-851).  send_slots / recv_slots hold the slots of
+ * all messages back to back, in message order.  Several messages may go to the same rank (a dimension cut in two has
+ * the same neighbour on both sides): every rank must then list them in the same order, RCCL matches the sends and
+ * receives between two ranks in the order they were issued.  One pack kernel, one grouped RCCL call and one unpack
+ * kernel per step and direction, whatever nmsg is.  Host arrays; copied. */
+typedef struct {
+    int   send_to, recv_from;
+    int   n_send, n_recv;
+    int   shift_index;
+    float shift[3];
+} nbx_dd_message_t;
+int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message_t *msg, const int *send_slots, const int *recv_slots);
+/* dd_move_x / dd_move_f for that pulse (or those messages), asynchronous on the non-local stream; every rank calls them.
  * Ordering: the pack kernel of dd_move_x (and nbnxn_hip_halo_pack_x) waits for the last write of home coordinates
  * that this library issued on the LOCAL stream (the H2D of nbnxn_hip_launch_kernel / nbnxn_hip_upload_xq_flat, the
  * gather of nbnxn_hip_copy_x_to_xq) -- for that write, not for a local kernel launched behind it, beside which the

@@ -1,8 +1,8 @@
-"""The multi-GPU form of the path on CPU: world_size 2 and 3 over gloo, with the oracle in place
-of the HIP kernels.  What is under test is everything bench.py --gpus N adds around the
-kernel: the slab cut, the halo zone and its grid, local / non-local lists, exclusions across
-the cut, the per-step coordinate and force messages, the periodic wrap at the bottom rank and
-the energy / shift-force reduction (gromacs-cosmo_amd/dd.py).  Reference: the same global
+"""The multi-GPU form of the path on CPU: world_size 1 to 8 over gloo (z slabs, and bricks in two and three
+dimensions), with the oracle in place of the HIP kernels.  What is under test is everything bench.py --gpus N adds
+around the kernel: the cut, the halo zones and their grids, local / non-local lists, exclusions across
+the cuts, the per-step coordinate and force messages (one per forward neighbour), the periodic crossings with their
+shift forces and the energy / shift-force reduction (gromacs-cosmo_amd/dd.py).  Reference: the same global
 system as ONE domain through the same oracle."""
 import os
 import socket
@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, model, min_ci_balanced, ret):
+def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims=(2,)):
     import gromacs_cosmo_amd as g
     from gromacs_cosmo_amd import abi, dd
     import oracle as O
@@ -40,8 +40,9 @@ def _worker(rank, world, port, model, min_ci_balanced, ret):
             # a cell skewed in the xy plane (box[YY][XX] != 0), box[ZZ] along z: decomposable along z
             glob = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, 0, 0))
         else:
-            glob = g.system.water_box(2, 2, 2 * world, model=model)
-        dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced)
+            gr = grid or (1, 1, world)
+            glob = g.system.water_box(2 * gr[0], 2 * gr[1], 2 * gr[2], model=model)
+        dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims)
         xq_t = torch.from_numpy(dom.xq)                 # aliases dom.xq
         f_t = torch.zeros((dom.npad, 3), dtype=torch.float64)
         halo = dd.HaloExchange(dom, xq_t, f_t)
@@ -84,7 +85,8 @@ def _worker(rank, world, port, model, min_ci_balanced, ret):
         ret[rank] = dict(err=err, e_lj=e[0], e_el=e[1], e_lj_ref=o["Vvdw"], e_el_ref=o["Vc"],
                          vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()),
                          nhome=dom.nhome, nhalo=dom.nhalo, natoms=glob.natoms,
-                         nsci=(dom.pl_local.nsci, dom.pl_nonlocal.nsci))
+                         nsci=(dom.pl_local.nsci, dom.pl_nonlocal.nsci), nmsg=len(dom.msgs), nzones=len(dom.zones),
+                         peers=sorted({m.recv_from for m in dom.msgs}))
     finally:
         dist.destroy_process_group()
 
@@ -102,6 +104,29 @@ def test_slab_decomposition_matches_single_domain(world, model, mcb):
         assert r["nhalo"] > 0 and r["nsci"][1] > 0
         # both sides are the double oracle on float32 coordinates; they differ by the float32 rounding
         # of z + box_z for atoms imported across the periodic wrap (~1e-7 of a distance)
+        assert r["err"] < 2e-6, r
+        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
+        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r
+        assert r["vir_err"] < 1e-5, r
+
+
+# Bricks in two and three dimensions: half shell with direct peers (4 messages per rank in 2-D, 13 in 3-D).  With two
+# ranks along a dimension the neighbour above is also the neighbour below (two messages between the same pair, with
+# different shifts); (3, 2, 1) has distinct neighbours along x.  One rank that is its own neighbour in all three
+# dimensions carries the 13-message step alone.
+@pytest.mark.parametrize("world,grid,self_dims,model,mcb", [
+    (4, (2, 2, 1), (), "spce", 0), (4, (1, 2, 2), (), "spc", 150), (2, (2, 1, 1), (), "spc", 0),
+    (6, (3, 2, 1), (), "spc", 0), (8, (2, 2, 2), (), "spce", 0), (1, (1, 1, 1), (0, 1, 2), "spce", 0), (1, (1, 1, 1), (0, 2), "spc", 0)])
+def test_brick_decomposition_matches_single_domain(world, grid, self_dims, model, mcb):
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, _free_port(), model, mcb, ret, grid, self_dims), nprocs=world, join=True)
+        res = [ret[r] for r in range(world)]
+    assert sum(r["nhome"] for r in res) == res[0]["natoms"]
+    ncut = sum(1 for d in range(3) if grid[d] > 1 or (world == 1 and d in self_dims))
+    for r in res:
+        assert r["nmsg"] == {1: 1, 2: 4, 3: 13}[ncut] and r["nzones"] == r["nmsg"] + 1
+        assert r["nhalo"] > 0 and r["nsci"][1] > 0
         assert r["err"] < 2e-6, r
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r

@@ -59,7 +59,7 @@ def worker(rank, world, port, device_halo):
             t("halo_pack_x", lambda: nb.halo_pack_x(p[0], h.n_send, h.shift, p[2], abi.NONLOCAL))
             t("halo_unpack_x", lambda: nb.halo_unpack_x(p[1], h.n_halo, p[3], abi.NONLOCAL))
             t("halo_pack_f", lambda: nb.halo_pack_f(p[1], h.n_halo, p[4], abi.NONLOCAL))
-            t("halo_unpack_f", lambda: nb.halo_unpack_f(p[0], h.n_send, p[5], h.wrap_shift, abi.NONLOCAL))
+            t("halo_unpack_f", lambda: nb.halo_unpack_f(p[0], h.n_send, p[5], h.seg[0][3] if h.seg else -1, abi.NONLOCAL))
         t("stream_wait", lambda: nb.stream_wait(abi.NONLOCAL, abi.LOCAL))
         t("_current_views", lambda: run._current_views())
 
