@@ -16,7 +16,7 @@ halo f).  The path's multi-GPU form here has the same data flow with a simpler z
     The reference's eighth shell (dd_zo / dd_zp3, domdec.c:433-449) imports from 7 zones in staged pulses that
     forward corner data through intermediate ranks (domdec.c:667-758) and computes zone x zone pairs; on a node
     whose 8 GPUs are all linked to each other every neighbour is one hop away, the faces carry nearly all of the
-    volume in both schemes (13x13x14 tiles on 2x2x2 ranks: 27 % of the home atoms here, 25 % there), and one grouped
+    volume in both schemes (13x13x14 tiles on 2x2x2 ranks: 28 % of the home atoms here, 26 % there), and one grouped
     RCCL call moves all messages at once.  Bricks must be thicker than rlist so that only neighbours interact;
   * per step: halo coordinates travel to the ranks that import them (plus the box vectors of the periodic
     boundaries they cross), halo forces travel back and are added to the owner's forces -- those that crossed a
