@@ -406,7 +406,15 @@ def main():
     # for --precondition seconds first; with K = 20 the timed region would otherwise sit inside the ramp.
     t_pre = time.perf_counter()
     n_pre = 0
-    while args.precondition > 0 and time.perf_counter() - t_pre < args.precondition:
+    def keep_preconditioning():
+        go = args.precondition > 0 and time.perf_counter() - t_pre < args.precondition
+        if decomposed and world > 1:
+            # every rank must run the same number of steps (each step is a set of matched messages): rank 0's clock decides
+            t = torch.tensor([1 if go else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+            dist.broadcast(t, 0)
+            go = bool(int(t.item()))
+        return go
+    while keep_preconditioning():
         for _ in range(100):
             step()
         finish()

@@ -647,7 +647,15 @@ inline int progressive_nsp_max(int nsp_max_av, int sci, int shift)
     unsigned h = (unsigned)sci * 2654435761u + (unsigned)shift * 40503u;
     h ^= h >> 15;
     const int   cls = (int)(h & 7u);
-    const float f   = cls < 6 ? 1.5f : (cls == 6 ? 0.75f : 0.4f);
+    float       f   = cls < 6 ? 1.5f : (cls == 6 ? 0.75f : 0.4f);
+    // tuning aid (tools/ab_prog.sh): NBNXN_PROG_FACTORS="f0,...,f7" replaces the eight class factors in THIS builder
+    // only; the device search keeps the built-in ones, so a list made with it is for kernel timing, not for the search tests
+    static const std::vector<float> env = [] {
+        std::vector<float> v;
+        if (const char *e = getenv("NBNXN_PROG_FACTORS")) { for (const char *q = e; *q;) { char *end; v.push_back(strtof(q, &end)); q = (*end == ',') ? end + 1 : end; if (end == q && *end) { break; } } }
+        return v;
+    }();
+    if (env.size() == 8) { f = env[cls]; }
     return std::max(NSUBC * 4 / 2 + 1, (int)(nsp_max_av * f));
 }
 

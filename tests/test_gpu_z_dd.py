@@ -357,7 +357,8 @@ def test_module_rccl_path_single_rank():
 
 def test_bench_starts_its_own_ranks_and_cuts_one_box():
     """`python bench.py --gpus 2 ... --strong` as the driver types it (no launcher): the script starts its two ranks
-    itself, before it touches the GPU, and cuts ONE box into two slabs (BASELINE configs[3] in small).  On this
+    itself, before it touches the GPU, and cuts ONE box into two slabs (BASELINE configs[3] in small); with a
+    preconditioning phase, whose length rank 0's clock decides for both ranks.  On this
     one-GPU box both ranks share cuda:0 over gloo (BENCH_REHEARSAL=1): the plumbing is what is checked, not a number."""
     import json
     import subprocess
@@ -366,7 +367,7 @@ def test_bench_starts_its_own_ranks_and_cuts_one_box():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BENCH_REHEARSAL"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--tiles", "2,2,4", "--strong", "--steps", "3",
-                        "--warmup", "1", "--precondition", "0"], env=env, capture_output=True, text=True, timeout=280)
+                        "--warmup", "1", "--precondition", "0.2"], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-800:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
