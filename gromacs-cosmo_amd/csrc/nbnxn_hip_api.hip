@@ -789,7 +789,12 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
         std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
         for (int b = 0; b < reserve; b++) { mask[b / 32] &= ~(1u << (b % 32)); }
         if (prop.multiProcessorCount % 32) { mask.back() &= (1u << (prop.multiProcessorCount % 32)) - 1; }
-        // a platform that does not take CU masks gets an ordinary stream: the run is correct without the reservation
+        // a platform that does not take CU masks gets an ordinary stream: the run is correct without the reservation.
+        // hipExtStreamCreateWithCUMask has no flags argument: the stream it makes is a BLOCKING one (it orders itself
+        // against the null stream), where every other stream of the module is hipStreamNonBlocking.  The module never
+        // uses the null stream and no ordering in it relies on that implicit synchronisation (every cross-stream
+        // dependency is an event); a host that puts work on the null stream sees it serialise with the masked local
+        // stream only.  The two-stream GPU tests run with the reservation on and off (tests/test_gpu_z_dd.py).
         if (hipExtStreamCreateWithCUMask(&nb->stream[0], (uint32_t)mask.size(), mask.data()) != hipSuccess)
         {
             (void)hipGetLastError();

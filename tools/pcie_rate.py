@@ -48,3 +48,21 @@ for kind in ("pageable", "pinned"):
         dt = (time.perf_counter() - t0) / n
         print(f"{kind:8s} host arrays, module event timing {str(timing):5s}: {dt * 1e3:.4f} ms per step incl. H2D xq + D2H f, "
               f"{p.pair_slots / dt / 1e9:.1f} Gpair/s", flush=True)
+        if timing:
+            t = nb.timings()
+            c = max(t.nb_c, 1)
+            print(f"         device-side event times per step: H2D {t.nb_h2d_t / c * 1e3:.1f} us, kernel {sum(t.ktime[a][b].t for a in range(2) for b in range(2)) / c * 1e3:.1f} us, "
+                  f"D2H {t.nb_d2h_t / c * 1e3:.1f} us", flush=True)
+            nb.reset_timings()
+    # host time of each call (pinned arrays, timing off): where the step's wall time goes
+    if kind == "pinned":
+        import collections
+        acc = collections.Counter()
+        for _ in range(200):
+            t0 = time.perf_counter(); nb.clear_outputs(fl)
+            t1 = time.perf_counter(); nb.launch_kernel(xq, fl)
+            t2 = time.perf_counter(); nb.launch_cpyback(f, fl)
+            t3 = time.perf_counter(); nb.wait_gpu(fl, abi.LOCAL, e_lj, e_el, fsh)
+            t4 = time.perf_counter()
+            acc["clear_outputs"] += t1 - t0; acc["launch_kernel"] += t2 - t1; acc["launch_cpyback"] += t3 - t2; acc["wait_gpu"] += t4 - t3
+        print("         host time per call (us): " + ", ".join(f"{k} {v / 200 * 1e6:.1f}" for k, v in acc.items()), flush=True)
