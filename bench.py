@@ -199,7 +199,7 @@ def cpu_threads():
     return max(1, min(share if share > 0 else avail, avail, 32))
 
 
-def _time_calls(fn, seconds, max_calls=400):
+def _time_calls(fn, seconds, max_calls=100000):
     fn()
     n, t0 = 0, time.perf_counter()
     while True:

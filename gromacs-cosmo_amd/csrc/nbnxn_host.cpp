@@ -659,6 +659,13 @@ inline int progressive_nsp_max(int nsp_max_av, int sci, int shift)
     return std::max(NSUBC * 4 / 2 + 1, (int)(nsp_max_av * f));
 }
 
+// tuning aid: NBNXN_NL_SPLIT_SCALE multiplies the pair budget of non-local list entries (both builders read it)
+static double nonlocal_split_scale()
+{
+    static const double v = [] { const char *e = getenv("NBNXN_NL_SPLIT_SCALE"); const double x = e ? atof(e) : 1.0; return x > 0 ? x : 1.0; }();
+    return v;
+}
+
 // get_nsubpair_max (nbnxn_search.c:4324-4408), local (single-grid) estimate
 int nsubpair_max(const Grid &g, float rlist, int min_ci_balanced, double frac_of_local)
 {
@@ -713,7 +720,7 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
     int nsp_max = -1;
     if (jz1 > jz0)
     {
-        nsp_max = nsubpair_max(gi, rlist, min_ci_balanced, iloc == NBX_LOCAL ? 1.0 : 0.25);
+        nsp_max = nsubpair_max(gi, rlist, min_ci_balanced, iloc == NBX_LOCAL ? 1.0 : 0.25 * nonlocal_split_scale());
     }
 
     // contiguous slices of i super-cells per part; parts are concatenated in order, so the

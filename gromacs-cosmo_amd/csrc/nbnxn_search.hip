@@ -1142,6 +1142,13 @@ int nbx_search_download_grid(const nbx_search *s, hipStream_t st, int *a, int *c
 
 namespace {
 
+// tuning aid: NBNXN_NL_SPLIT_SCALE multiplies the pair budget of non-local list entries (both builders read it)
+static double nonlocal_split_scale()
+{
+    static const double v = [] { const char *e = getenv("NBNXN_NL_SPLIT_SCALE"); const double x = e ? atof(e) : 1.0; return x > 0 ? x : 1.0; }();
+    return v;
+}
+
 // get_nsubpair_max (nbnxn_search.c:4324-4408), estimate from the home grid, as in the host builder
 int nsubpair_max(const nbx_search &s, float rlist, int min_ci_balanced, double frac_of_local)
 {
@@ -1251,7 +1258,7 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     h1[0] = s->h_pin[1]; h1[1] = s->h_pin[2];
     const int ncj4  = h1[0];
     s->nsubc_tot0   = h1[1];
-    const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced, same ? 1.0 : 0.25);
+    const int nsp_max = nsubpair_max(*s, rlist, min_ci_balanced, same ? 1.0 : 0.25 * nonlocal_split_scale());
 
     if (s->cj4.reserve((size_t)ncj4 + 1) || s->need_excl.reserve(2 * (size_t)ncj4 + 1) || s->excl_rank.reserve(2 * (size_t)ncj4 + 1)) { return 1; }
     S_TRY(hipMemsetAsync(s->need_excl.p, 0, (2 * (size_t)ncj4 + 1) * sizeof(int), st));
