@@ -861,3 +861,35 @@ def test_benchmark_switches_of_the_cuda_module(env, bins):
         b = out[k]["bins"]
         assert b[prune][ener] == 1 and sum(map(sum, b)) == 1, (k, b)
         assert relrms(np.array(out[k]["f"]), o["f"]) < FORCE_RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["spc3240_rf09", "spce3240_ewald09"])
+def test_reference_named_calls_run_a_step(name, tmp_path):
+    """The drop-in boundary at run time: a C program compiled against the REFERENCE's own headers
+    (oracle/binding_check.c, built into oracle/_ref where the reference tree exists) builds the reference's objects --
+    gmx_gpu_info_t, nonbonded_verlet_t, nbnxn_atomdata_t with pinned x and f, nbnxn_pairlist_t, interaction_const_t --
+    and makes mdrun's calls by their reference names (detect_cuda_gpus ... init_gpu, nbnxn_cuda_init, _init_const,
+    _init_atomdata, _upload_shiftvec, _init_pairlist, _launch_kernel, _launch_cpyback, _wait_gpu, _clear_outputs,
+    _get_timings, _free, free_gpu), all resolved by include/nbnxn_hip_gmx.h over libnbnxn_hip.so.  Forces of an energy
+    step and of a force-only step, energies and the virial's shift forces against the oracle."""
+    import subprocess
+    from util import write_step_file, read_step_result
+    exe = os.path.join(ROOT, "oracle", "_ref", "binding_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/binding_check not built (needs /root/reference at build time)")
+    p, ip, d = load_small(name)
+    o = O.kernel_gpu_list(p.xq, p.type, p.ntype, p.nbfp, p.shift_vec, p.pl, ip)
+    fin, fout = str(tmp_path / "step.in"), str(tmp_path / "step.out")
+    write_step_file(fin, p, ip)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+    res = read_step_result(fout, p.natoms)
+    assert relrms(res.f1, o["f"]) < FORCE_RTOL and relrms(res.f2, o["f"]) < FORCE_RTOL
+    assert abs(res.e_lj - o["Vvdw"]) < ENERGY_RTOL * abs(o["Vvdw"]) and abs(res.e_el - o["Vc"]) < ENERGY_RTOL * abs(o["Vc"])
+    vir = virial_from(p.xq, res.f1, p.shift_vec, res.fshift)
+    vir_o = virial_from(p.xq, o["f"], p.shift_vec, o["fshift"])
+    assert np.abs(vir - vir_o).max() < 1e-5 * np.abs(vir_o).max()
+    assert res.analytical == int(ip.el_type != abi.EL_RF) and res.min_ci_balanced > 0 and res.ndev >= 1
+    # the timing table books the first launch on the new list as prune + energies, the second as neither (nbnxn_cuda.cu:633)
+    assert res.nb_c == 2 and res.c_prune_ener == 1 and res.c_plain == 1

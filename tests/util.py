@@ -129,3 +129,35 @@ def ljpme_grid_c6(nbfp, ntype, comb_rule, ti, tj):
         return c[ti, 0] * c[tj, 0]
     sigma, eps = c[ti, 0] + c[tj, 0], c[ti, 1] * c[tj, 1]
     return eps * sigma ** 6
+
+
+def write_step_file(path, p, ip):
+    """The input of `oracle/_ref/binding_check <in> <out>` (oracle/binding_check.c, step_header_t): one prepared
+    system and its list as raw arrays, for the run of a step through the reference's own entry-point names."""
+    f32 = lambda v: np.float32(v)
+    head_i = np.zeros(16, dtype=np.int32)
+    head_i[:10] = [0x4e42584e, p.natoms, p.ntype, p.pl.nsci, p.pl.ncj4, p.pl.nexcl, p.pl.nci_tot,
+                   abi.EEL_RF if ip.el_type == abi.EL_RF else abi.EEL_PME, int(getattr(ip, "vdwtype", 0)), int(getattr(ip, "vdw_modifier", 1))]
+    head_f = np.zeros(16, dtype=np.float32)
+    head_f[:12] = [f32(ip.rcoulomb), f32(ip.rvdw), f32(ip.rlist), f32(ip.epsfac), f32(ip.k_rf), f32(ip.c_rf), f32(ip.ewaldcoeff_q),
+                   f32(ip.sh_ewald), f32(ip.disp_cpot), f32(ip.rep_cpot), f32(ip.epsilon_r), f32(ip.epsilon_rf)]
+    with open(path, "wb") as fh:
+        fh.write(head_i.tobytes())
+        fh.write(head_f.tobytes())
+        for a, dt in ((p.xq, np.float32), (p.type, np.int32), (p.nbfp, np.float32), (p.shift_vec, np.float32)):
+            fh.write(np.ascontiguousarray(a, dtype=dt).tobytes())
+        fh.write(p.pl.sci[:p.pl.nsci].tobytes())
+        fh.write(p.pl.cj4[:p.pl.ncj4].tobytes())
+        fh.write(p.pl.excl[:p.pl.nexcl].tobytes())
+
+
+def read_step_result(path, natoms):
+    raw = open(path, "rb").read()
+    info = np.frombuffer(raw, dtype=np.int32, count=8)
+    e = np.frombuffer(raw, dtype=np.float32, count=2, offset=32)
+    fshift = np.frombuffer(raw, dtype=np.float32, count=135, offset=40).reshape(45, 3)
+    f1 = np.frombuffer(raw, dtype=np.float32, count=natoms * 3, offset=40 + 540).reshape(natoms, 3)
+    f2 = np.frombuffer(raw, dtype=np.float32, count=natoms * 3, offset=40 + 540 + natoms * 12).reshape(natoms, 3)
+    return SimpleNamespace(min_ci_balanced=int(info[0]), analytical=int(info[1]), nb_c=int(info[2]), c_prune_ener=int(info[3]),
+                           c_plain=int(info[4]), device=int(info[5]), ndev=int(info[6]), dev_info_size=int(info[7]),
+                           e_lj=float(e[0]), e_el=float(e[1]), fshift=fshift, f1=f1, f2=f2)
