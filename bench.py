@@ -433,6 +433,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k] if k % args.event_every == 0 else None)
+    t_issued = time.perf_counter()      # the host has issued every step; the device may still be working
     finish()
     sync()
     if decomposed:
@@ -482,6 +483,7 @@ def main():
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, numbers meaningless)" if rehearsal else ""),
             "ns_per_day": 86400.0 * DT_FS * 1e-6 / (ms_per_step * 1e-3),
             "ns_per_day_note": f"nonbonded only, dt = {DT_FS} fs",
+            "host_issue_ms_per_step": 1e3 * (t_issued - t0) / args.steps,
             "config": dict({"workload": f"{model.upper()} water {natoms} atoms ({'x'.join(map(str, tiles))} spc216 tiles"
                                         f"{' per GPU' if world > 1 and not args.strong else ''}{', one box cut into ' + (str(world) + ' z slabs' if not args.dd_grid else args.dd_grid.replace(',', 'x') + ' bricks') if world > 1 and args.strong else ''}), "
                                         f"{'analytical Ewald real-space' if args.workload == 'ewald' else 'reaction-field'} + LJ, "
