@@ -3,6 +3,8 @@
 // part of nbnxn_cuda.cu; structure is our own: one handle, two HIP streams, plain
 // hipMalloc'd arrays with 20 % over-allocation, hipEvent timing.
 #include <hip/hip_runtime.h>
+
+#include <chrono>
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound at run time (dd_bind)
 #include <dlfcn.h>
 
@@ -1961,4 +1963,47 @@ int nbnxn_hip_dd_sum_outputs(nbnxn_hip_ptr_t nb, int iloc)
     HIP_TRY(hipSetDevice(nb->device));
     RCCL_TRY(g_rccl.AllReduce(nb->out, nb->out, (size_t)NBX_OUT_SLOTS * NBX_OUT_STRIDE, ncclFloat, ncclSum, nb->dd_comm, dd_stream(nb, iloc)));
     return 0;
+}
+
+int nbnxn_hip_dd_step(nbnxn_hip_ptr_t nb, int flags, int sum_last_outputs, int exchange_beside_local, void *ev_before_local,
+                      void *ev_after_local)
+{
+    // One decomposed step with resident coordinates, issued from ONE call: the host's time to issue a step is what
+    // limits a short step, and every call through a foreign-function layer adds to it.
+    if (check_dd(nb)) { return 1; }
+    if (!nb->two_streams) { return nbx_fail("dd_step needs a handle with a local and a non-local stream"); }
+    if (nb->dd_nmsg == 0) { return nbx_fail("dd_step before dd_set_pulse / dd_set_messages"); }
+    HIP_TRY(hipSetDevice(nb->device));
+    // NBNXN_DD_STEP_PROFILE=1: host time of every part, printed every 1000 steps (a measurement aid)
+    static const bool prof = getenv("NBNXN_DD_STEP_PROFILE") != nullptr;
+    static double     acc[7];
+    static long       nstep = 0;
+    auto              now   = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double            t     = prof ? now() : 0;
+    auto              lap   = [&](int k) { if (prof) { const double u = now(); acc[k] += u - t; t = u; } };
+    if (!exchange_beside_local && nbnxn_hip_dd_move_x(nb)) { return 1; }     // behind the last step's returned forces
+    if (!exchange_beside_local) { lap(3); }
+    if (sum_last_outputs && nbnxn_hip_dd_sum_outputs(nb, NBX_LOCAL)) { return 1; }
+    lap(0);
+    if (nbnxn_hip_clear_outputs(nb, flags)) { return 1; }
+    lap(1);
+    if (ev_before_local) { HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev_before_local), nb->stream[NBX_LOCAL])); }
+    if (launch_impl(nb, nullptr, flags, NBX_LOCAL)) { return 1; }
+    if (ev_after_local) { HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev_after_local), nb->stream[NBX_LOCAL])); }
+    lap(2);
+    if (exchange_beside_local && nbnxn_hip_dd_move_x(nb)) { return 1; }     // beside the local kernel
+    if (exchange_beside_local) { lap(3); }
+    if (launch_impl(nb, nullptr, flags, NBX_NONLOCAL)) { return 1; }
+    lap(4);
+    if (nbnxn_hip_dd_move_f(nb)) { return 1; }
+    lap(5);
+    const int rc = nbnxn_hip_stream_wait(nb, NBX_LOCAL, NBX_NONLOCAL);
+    lap(6);
+    if (prof && ++nstep % 1000 == 0)
+    {
+        fprintf(stderr, "dd_step host us/step: sum_outputs %.1f clear %.1f local launch %.1f move_x %.1f non-local launch %.1f move_f %.1f stream_wait %.1f\n",
+                acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000, acc[4] / 1000, acc[5] / 1000, acc[6] / 1000);
+        for (double &v : acc) { v = 0; }
+    }
+    return rc;
 }

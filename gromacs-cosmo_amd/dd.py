@@ -542,6 +542,7 @@ class SlabRun:
         self.device_halo, self.rccl_direct = device_halo, rccl_direct
         self._reduction_owed = False
         self.exchange_beside_local = nb.reserved_cus() > 0 and os.environ.get("NBNXN_DD_X_FIRST") != "1"
+        self.one_call = os.environ.get("NBNXN_DD_STEP_CALLS") != "many"
         if rccl_direct:
             self.halo = RcclHalo(nb, dom, self.dev)
         else:
@@ -609,6 +610,17 @@ class SlabRun:
         flush() issues the one still owed before anybody reads the energies."""
         nb, fl = self.nb, self.flags
         beside = self.exchange_beside_local               # the local stream leaves CUs free: RCCL's kernel finds room
+        if self.one_call:
+            # the same sequence from one call through the C ABI (nbnxn_hip_dd_step): the host's issue time limits the step
+            h0 = h1 = None
+            if ev:
+                for e in ev:
+                    if not e.cuda_event:
+                        e.record(self.s_loc)              # torch makes the event on its first record
+                h0, h1 = ev[0].cuda_event, ev[1].cuda_event
+            nb.dd_step(fl, self._reduction_owed, beside, h0, h1)
+            self._reduction_owed = bool(fl & abi.FORCE_VIRIAL)
+            return
         if not beside:
             nb.dd_move_x()                                # non-local stream, behind the last step's returned forces
         self.flush()                                      # local stream: the last step's slot reduction, if owed

@@ -645,6 +645,14 @@ int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb);
 /* in-place ncclAllReduce(sum) of the output slots in use, on the stream of iloc (order it after both
  * kernels with nbnxn_hip_stream_wait) */
 int nbnxn_hip_dd_sum_outputs(nbnxn_hip_ptr_t nb, int iloc);
+/* One decomposed step with resident coordinates from ONE call (the host's time to issue a step limits a short step):
+ * [dd_move_x, if the exchange is not to run beside the local kernel] -> [dd_sum_outputs of the LAST step's slots, if
+ * sum_last_outputs] -> clear_outputs -> local kernel -> [dd_move_x beside it] -> non-local kernel -> dd_move_f ->
+ * nbnxn_hip_stream_wait(LOCAL, NONLOCAL).  ev_before_local / ev_after_local: hipEvent_t handles recorded around the
+ * local kernel on the local stream (NULL: none).  The sequence of gromacs-cosmo_amd/dd.py::SlabRun._step_rccl_direct;
+ * stands where sim_util.c:1012-1212 interleaves launches with dd_move_x / dd_move_f. */
+int nbnxn_hip_dd_step(nbnxn_hip_ptr_t nb, int flags, int sum_last_outputs, int exchange_beside_local, void *ev_before_local,
+                      void *ev_after_local);
 /* destroys the communicator and the halo buffers (nbnxn_hip_free does it too) */
 int nbnxn_hip_dd_finish(nbnxn_hip_ptr_t nb);
 
