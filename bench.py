@@ -311,6 +311,7 @@ def main():
         # is this command's output.
         raise SystemExit(self_launch(args.gpus))
 
+    print(f"[bench] importing torch (the first import on a fresh box can take a minute or two)", file=sys.stderr, flush=True)
     import torch
     import torch.distributed as dist
     import gromacs_cosmo_amd as g
@@ -339,6 +340,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    t_start = time.perf_counter()
+
+    def progress(what):
+        # one line per phase on stderr: a long run shows where it is (and a harness that watches for output sees it alive)
+        print(f"[bench rank {rank}] {time.perf_counter() - t_start:7.1f} s  {what}", file=sys.stderr, flush=True)
 
     tiles = tuple(int(t) for t in args.tiles.split(","))
     ener = not args.force_only
@@ -399,6 +406,7 @@ def main():
         if args.mcb >= 0 or args.variant >= 0 or args.no_split:
             raise SystemExit("--mcb/--variant/--no-split are single-GPU A/B switches")
 
+    progress(f"set up: {natoms} atoms, {parallelism}")
     finish = run.flush if decomposed else (lambda: None)   # what the last step left for the next one to issue
     # Preconditioning, untimed and before the W warm-up steps: the GPU's clock governor takes ~100 ms of load to reach
     # the frequency it then sustains (measured on the box: the same kernel runs 81 us in the first 20 ms of load and
@@ -422,6 +430,7 @@ def main():
         n_pre += 100
     if decomposed:
         dist.barrier()
+    progress(f"preconditioned: {n_pre} steps")
     for _ in range(args.warmup):
         step()
     finish()
@@ -440,6 +449,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
+    progress(f"timed {args.steps} steps: {1e3 * wall / args.steps:.4f} ms per step")
     kernel_ms_raw = float(np.mean([a.elapsed_time(b) for a, b in ev[::args.event_every]]))   # the nonbonded kernel alone, HIP events on its stream
     # an event pair with nothing between its records reads ~4 us on this stack: calibrate and subtract,
     # so that the figure is comparable with rocprofv3's dispatch begin/end duration of the same kernel

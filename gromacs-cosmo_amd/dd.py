@@ -496,7 +496,15 @@ class SlabRun:
         self.natoms_global = glob.natoms
         self.nb = nb = gpu.NbnxnHip(local_rank, local_and_nonlocal=True)
         mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced
+        verbose = os.environ.get("NBNXN_DD_VERBOSE") == "1"
+        import time as _time
+        _t0 = _time.perf_counter()
+
+        def say(what):
+            if verbose:
+                print(f"[dd rank {rank}] {_time.perf_counter() - _t0:6.1f} s  {what}", file=sys.stderr, flush=True)
         self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims)
+        say(f"domain built: {dom.nhome} home + {dom.nhalo} halo atoms, lists {dom.pl_local.nsci} / {dom.pl_nonlocal.nsci} entries")
         nb.init_const(ip, dom.ntype, dom.nbfp)
         if device_search:
             # grids and both lists made on the device; the host-side builder's results, which the
@@ -517,8 +525,10 @@ class SlabRun:
             nb.init_pairlist(dom.pl_nonlocal, abi.NONLOCAL)
             assert nb.verify_pairlist(dom.pl_local, abi.LOCAL) == 0
             assert nb.verify_pairlist(dom.pl_nonlocal, abi.NONLOCAL) == 0
+        say("lists on the device")
         # first pass the reference way: host xq in, forces out, both lists pruned, streams drained
         self.f_first, self.e_first = nb.compute_both(dom.xq, flags)
+        say("first pass done")
         d_xq, _, _ = nb.device_buffers()
         self.xq_t = torch.as_tensor(_DevArray(d_xq, (dom.npad, 4)), device=self.dev)
         # the clear is folded into the kernel launches: two output buffers alternate, so the
