@@ -136,10 +136,13 @@ def test_slabrun_one_rank_over_rccl(model, rccl_direct, reserve_cus, monkeypatch
     oracle."""
     # both kinds of local stream: with the CU reservation (a CU-masked stream, the coordinate exchange issued beside the
     # local kernel) and without it (an ordinary non-blocking stream, the exchange issued first)
+    # ... and both ways of issuing the module's step: from one call (nbnxn_hip_dd_step, the default) and as seven calls
     if reserve_cus == "0":
         monkeypatch.setenv("GMX_HIP_NB_RESERVE_CUS", "0")
+        monkeypatch.setenv("NBNXN_DD_STEP_CALLS", "many")
     else:
         monkeypatch.delenv("GMX_HIP_NB_RESERVE_CUS", raising=False)
+        monkeypatch.delenv("NBNXN_DD_STEP_CALLS", raising=False)
     with mp.Manager() as m:
         ret = m.dict()
         _watch(mp.spawn(_worker, args=(1, _free_port(), model, True, ret, "nccl", rccl_direct), nprocs=1, join=False))
