@@ -300,6 +300,8 @@ def main():
     ap.add_argument("--precondition", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up steps, so that the timed region runs at the clock the GPU sustains")
     ap.add_argument("--dd-grid", default="", help="ranks along x,y,z (default 1,1,N: z slabs); e.g. 2,2,2 for --gpus 8")
+    ap.add_argument("--dd-scheme", default="half", choices=["half", "eighth"],
+                    help="half shell with home i-clusters only (default) or the reference's eighth shell with pairs between imported zones")
     ap.add_argument("--dd-self-dims", default="2", help="with --dd-self: the dimensions the one rank is its own neighbour in (0,1,2 = the 13-message step)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --tiles is the whole box, cut into --gpus slabs (default: --tiles per GPU)")
@@ -391,7 +393,7 @@ def main():
         grid = tuple(int(v) for v in args.dd_grid.split(",")) if args.dd_grid else (1, 1, world)
         self_dims = tuple(int(v) for v in args.dd_self_dims.split(",")) if args.dd_self else ()
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong, grid=grid,
-                         self_dims=self_dims)
+                         self_dims=self_dims, scheme=args.dd_scheme)
         rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
@@ -400,7 +402,7 @@ def main():
         step = run.step          # step(ev) records ev around the local kernel
         stream = torch.cuda.ExternalStream(run.nb.stream(abi.LOCAL))
         sync = lambda: torch.cuda.synchronize()
-        shape = "z slabs" if grid == (1, 1, world) and self_dims in ((), (2,)) else f"{grid[0]}x{grid[1]}x{grid[2]} bricks, half shell, {len(run.dom.msgs)} direct peers' messages"
+        shape = "z slabs" if grid == (1, 1, world) and self_dims in ((), (2,)) and args.dd_scheme == "half" else f"{grid[0]}x{grid[1]}x{grid[2]} bricks, {args.dd_scheme} shell, {len(run.dom.msgs)} direct peers' messages"
         parallelism = f"dd{world}{' (one rank, its own neighbour)' if world == 1 else ''} ({shape}, RCCL halo x/f " + ("issued by the HIP module)" if rccl_direct else "through torch.distributed)")
         cfg_extra = run.describe()
         if args.mcb >= 0 or args.variant >= 0 or args.no_split:

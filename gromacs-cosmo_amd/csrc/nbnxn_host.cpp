@@ -696,7 +696,29 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
 {
     if (!h) { return fail("null handle"); }
     if (h->grids.empty()) { return fail("no grid: call nbnxn_host_put_on_grid first"); }
+    // the home zone against itself, or against every halo zone (nbnxn_search.c:5652-5699 with one i-zone)
+    const int zp[3] = {0, iloc == NBX_LOCAL ? 0 : 1, iloc == NBX_LOCAL ? 1 : (int)h->grids.size()};
+    return nbnxn_host_make_pairlist_zones(h, iloc, 1, zp, rlist, excl_index, excl_a, min_ci_balanced, xq);
+}
+
+// The general form: the list of zone pairs {i-zone, first j-zone, end j-zone} that the reference takes from its domain
+// decomposition (dd_zp3 / dd_zp2 / dd_zp1, domdec.c:433-449; the i-zone loop of nbnxn_make_pairlist,
+// nbnxn_search.c:5652-5699): i-clusters may lie in a halo zone.
+int nbnxn_host_make_pairlist_zones(nbnxn_host_ptr_t h, int iloc, int nzp, const int *zone_pairs, float rlist,
+                                   const int *excl_index, const int *excl_a, int min_ci_balanced, const float *xq)
+{
+    if (!h) { return fail("null handle"); }
+    if (h->grids.empty()) { return fail("no grid: call nbnxn_host_put_on_grid first"); }
     if (iloc != NBX_LOCAL && iloc != NBX_NONLOCAL) { return fail("bad iloc %d", iloc); }
+    if (nzp < 1 || !zone_pairs) { return fail("no zone pairs"); }
+    for (int z = 0; z < nzp; z++)
+    {
+        const int iz = zone_pairs[3 * z], j0 = zone_pairs[3 * z + 1], j1 = zone_pairs[3 * z + 2];
+        if (iz < 0 || iz >= (int)h->grids.size() || j0 < 0 || j1 > (int)h->grids.size() || j0 > j1)
+        {
+            return fail("zone pair %d = {%d, %d, %d} outside the %zu gridded zones", z, iz, j0, j1, h->grids.size());
+        }
+    }
     for (int d = 0; d < 3; d++)
     {
         if (h->shp[d] && h->box[d] < 2 * rlist)
@@ -712,26 +734,28 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
     // shift range (nbnxn_search.c:4906-4927): a skewed box can need two box lengths in x
     int shp[3] = {h->shp[0], h->shp[1], h->shp[2]};
     if (shp[0] && h->box[0] - std::fabs(h->byx) - std::fabs(h->bzx) < rlist) { shp[0] = 2; }
-    const Grid &gi  = h->grids[0];
     const float rl2 = rlist * rlist;
-    const int   jz0 = (iloc == NBX_LOCAL) ? 0 : 1;
-    const int   jz1 = (iloc == NBX_LOCAL) ? 1 : (int)h->grids.size();
+    // the pair budget of an entry comes from the home grid (get_nsubpair_max, nbnxn_search.c:4324-4408)
+    const int nsp_max = nsubpair_max(h->grids[0], rlist, min_ci_balanced, iloc == NBX_LOCAL ? 1.0 : 0.25 * nonlocal_split_scale());
 
-    int nsp_max = -1;
-    if (jz1 > jz0)
+    std::vector<PartList> parts;
+    for (int zpi = 0; zpi < nzp; zpi++)
     {
-        nsp_max = nsubpair_max(gi, rlist, min_ci_balanced, iloc == NBX_LOCAL ? 1.0 : 0.25 * nonlocal_split_scale());
-    }
+    const int   izone = zone_pairs[3 * zpi];
+    const Grid &gi    = h->grids[izone];
+    const int   jz0 = zone_pairs[3 * zpi + 1], jz1 = zone_pairs[3 * zpi + 2];
+    if (jz1 <= jz0 || gi.nc == 0) { continue; }
 
     // contiguous slices of i super-cells per part; parts are concatenated in order, so the
     // result does not depend on the thread count
-    const int npart = std::max(1, std::min(64, gi.nc / 8));
-    std::vector<PartList> parts(npart);
+    const int    npart = std::max(1, std::min(64, gi.nc / 8));
+    const size_t part0 = parts.size();
+    parts.resize(part0 + npart);
 
 #pragma omp parallel for schedule(dynamic, 1)
     for (int p = 0; p < npart; p++)
     {
-        PartList &pl = parts[p];
+        PartList &pl = parts[part0 + p];
         const int s0 = (int)((long long)gi.nc * p / npart);
         const int s1 = (int)((long long)gi.nc * (p + 1) / npart);
         BB    bb_ci[NSUBC];
@@ -754,7 +778,7 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
             for (int jz = jz0; jz < jz1; jz++)
             {
                 const Grid &gj       = h->grids[jz];
-                const bool same_grid = (jz == 0);
+                const bool same_grid = (jz == izone);
                 const float bbx = 0.5f * (gi.sx + gj.sx) / 2, bby = 0.5f * (gi.sy + gj.sy) / 2;
                 // boundingbox_only_distance2 (:4721-4757)
                 const float rbb2 = sqr(std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby)));
@@ -865,6 +889,8 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
             }
         }
     }
+
+    }   // zone pairs
 
     // combine_nblists (:4466-4560): concatenate, renumber cj4 and excl indices
     List &L = h->lists[iloc];

@@ -18,6 +18,10 @@ halo f).  The path's multi-GPU form here has the same data flow with a simpler z
     whose 8 GPUs are all linked to each other every neighbour is one hop away, the faces carry nearly all of the
     volume in both schemes (13x13x14 tiles on 2x2x2 ranks: 28 % of the home atoms here, 26 % there), and one grouped
     RCCL call moves all messages at once.  Bricks must be thicker than rlist so that only neighbours interact;
+  * scheme="eighth" is the reference's own zone scheme with the same direct messages: the 1 / 3 / 7 zones of dd_zo, and the
+    zone pairs of dd_zp1 / dd_zp2 / dd_zp3 in the lists, so the non-local list also holds pairs BETWEEN imported zones and its
+    i-clusters are not all home clusters (what stock mdrun's search hands the kernel under domain decomposition).  The host
+    builder makes those lists (nbnxn_host_make_pairlist_zones); the device search pairs home i-clusters only;
   * per step: halo coordinates travel to the ranks that import them (plus the box vectors of the periodic
     boundaries they cross), halo forces travel back and are added to the owner's forces -- those that crossed a
     boundary also to the shift force of that crossing, the rule of dd_move_f (domdec.c:837-851); {e_lj, e_el,
@@ -73,10 +77,39 @@ def coords_of(rank, grid):
     return (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
 
 
-def forward_offsets(decomp):
-    """The half shell over the cut dimensions: offsets (dx, dy, dz) with (dz, dy, dx) > (0, 0, 0)."""
+def forward_offsets(decomp, scheme="half"):
+    """The zones a rank imports, as offsets (dx, dy, dz) of the rank that owns them.
+    "half": the half shell over the cut dimensions, offsets in {-1, 0, 1}^3 with (dz, dy, dx) > (0, 0, 0).
+    "eighth": the reference's eighth shell, the zones 1 .. 2^ndim - 1 of dd_zo (domdec.c:432-434) over the cut dimensions
+    in x, y, z order; with it the lists also hold pairs between imported zones (eighth_shell_zone_pairs)."""
+    if scheme == "eighth":
+        dims = [d for d in range(3) if decomp[d]]
+        offs = []
+        for zo in DD_ZO[1:2 ** len(dims)]:
+            o = [0, 0, 0]
+            for k, d in enumerate(dims):
+                o[d] = zo[k]
+            offs.append(tuple(o))
+        return offs
     r = [(-1, 0, 1) if d else (0,) for d in decomp]
     return [(dx, dy, dz) for dz in r[2] for dy in r[1] for dx in r[0] if (dz, dy, dx) > (0, 0, 0)]
+
+
+# The DD zone order and the zone pairs of the reference (mdlib/domdec.c:432-449): {i-zone, first j-zone, end j-zone}.
+# i-zones with a non-zero component see only j-zones with that component 0, so every pair of bricks meets on one rank.
+DD_ZO = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 1, 1), (0, 0, 1), (1, 0, 1), (1, 1, 1))
+DD_ZP = {1: ((0, 0, 2),), 2: ((0, 0, 4), (1, 3, 4)), 3: ((0, 0, 8), (1, 3, 6), (2, 5, 6), (3, 5, 7))}
+
+
+def eighth_shell_zone_pairs(ndim):
+    """(local, non-local) zone pairs of the eighth shell: home x home is the local list, the rest of dd_zp the non-local."""
+    nonlocal_ = []
+    for iz, j0, j1 in DD_ZP[ndim]:
+        if iz == 0:
+            nonlocal_.append((0, 1, j1))
+        else:
+            nonlocal_.append((iz, j0, j1))
+    return ((0, 0, 1),), tuple(nonlocal_)
 
 
 @dataclass
@@ -115,6 +148,7 @@ class Domain:
     excl_a: np.ndarray = None
     rlist: float = 0.0
     min_ci_balanced: int = 0
+    scheme: str = "half"     # "half": half shell, home i-clusters only; "eighth": the reference's zones and zone pairs
 
     @property
     def pair_slots(self):
@@ -170,7 +204,7 @@ def _exchange_split(send, in_splits, recv, out_splits):
     dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits)
 
 
-def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,)):
+def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,), scheme="half"):
     """Cuts rank `rank`'s brick out of the global system `glob` (every rank holds the synthetic
     global topology; coordinates of imported atoms still arrive by message, as they would in a
     run), grids home and halo zones, and builds both lists.  grid = ranks along (x, y, z), default z slabs."""
@@ -209,7 +243,9 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
     rl = np.float32(ip.rlist)
 
     msgs, sels, halo_id_parts, halo_x_parts = [], [], [], []
-    for o in forward_offsets(decomp):
+    if scheme not in ("half", "eighth"):
+        raise ValueError(f"unknown decomposition scheme {scheme!r}")
+    for o in forward_offsets(decomp, scheme):
         # what the rank at me - o imports from me: my atoms within rlist of the face / edge / corner we share
         sel = np.ones(nhome, dtype=bool)
         t = [0, 0, 0]
@@ -254,6 +290,8 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
     a0 = nhome
     for m, xh in zip(msgs, halo_x_parts):
         if m.n_recv == 0:
+            if scheme == "eighth":
+                raise ValueError(f"zone {m.offset} of the eighth shell is empty: the zone pairs need every zone on the grid")
             continue
         z0 = [c1[d] if m.offset[d] == 1 else (c0[d] - float(rl) if m.offset[d] == -1 else c0[d]) for d in range(3)]
         z1 = [c1[d] + float(rl) if m.offset[d] == 1 else (c0[d] if m.offset[d] == -1 else c1[d]) for d in range(3)]
@@ -291,8 +329,11 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
     excl_index = np.cumsum(excl_index).astype(np.int32)
     excl_a = partners.astype(np.int32)
 
-    pl_local = host.make_pairlist(abi.LOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
-    pl_nonlocal = host.make_pairlist(abi.NONLOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced)
+    # half shell: home x home and home x every imported zone; eighth shell: the reference's zone pairs, with pairs
+    # between imported zones in the non-local list (its i-clusters are then not all home clusters)
+    zp_local, zp_nonlocal = (None, None) if scheme == "half" else eighth_shell_zone_pairs(sum(decomp))
+    pl_local = host.make_pairlist(abi.LOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced, zone_pairs=zp_local)
+    pl_nonlocal = host.make_pairlist(abi.NONLOCAL, ip.rlist, xq, excl_index, excl_a, min_ci_balanced, zone_pairs=zp_nonlocal)
     cell = host.cell_index()
     send_slots = np.concatenate([cell[sel] for sel in sels]).astype(np.int64) if sels else np.zeros(0, np.int64)
     return Domain(rank=rank, world=world, grid=grid, decomp=decomp, box=box, box_search=box_search, lo=lo, hi=hi, nhome=nhome, nhalo=nhalo,
@@ -301,7 +342,7 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
                   npad=len(xq), npad_local=host.natoms_padded_local, msgs=msgs,
                   send_slots=send_slots, halo_slots=cell[nhome:nhome + nhalo].astype(np.int64),
                   zones=zones, x_all=x_all, type_all=glob.type[ids_all].astype(np.int32), q_all=glob.q[ids_all].astype(np.float32),
-                  excl_index=excl_index, excl_a=excl_a, rlist=float(ip.rlist), min_ci_balanced=int(min_ci_balanced))
+                  excl_index=excl_index, excl_a=excl_a, rlist=float(ip.rlist), min_ci_balanced=int(min_ci_balanced), scheme=scheme)
 
 
 class _Layout:
@@ -483,7 +524,7 @@ class SlabRun:
     (strong scaling, BASELINE configs[3]) cut into grid = (nx, ny, nz) bricks of equal size, default `world` z slabs."""
 
     def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None, device_search=True,
-                 device_halo=True, rccl_direct=False, strong=False, grid=None, self_dims=(2,)):
+                 device_halo=True, rccl_direct=False, strong=False, grid=None, self_dims=(2,), scheme="half"):
         """device_halo: halo buffers packed by the module's kernels (else torch indexing operations), messages
         through torch.distributed.  rccl_direct: everything, messages included, issued by the module on its own
         RCCL communicator (needs one GPU per rank)."""
@@ -503,7 +544,9 @@ class SlabRun:
         def say(what):
             if verbose:
                 print(f"[dd rank {rank}] {_time.perf_counter() - _t0:6.1f} s  {what}", file=sys.stderr, flush=True)
-        self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims)
+        self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims, scheme=scheme)
+        if scheme == "eighth":
+            device_search = False      # the device search pairs home i-clusters only: the eighth shell's lists come from the host builder
         say(f"domain built: {dom.nhome} home + {dom.nhalo} halo atoms, lists {dom.pl_local.nsci} / {dom.pl_nonlocal.nsci} entries")
         nb.init_const(ip, dom.ntype, dom.nbfp)
         if device_search:
@@ -520,6 +563,7 @@ class SlabRun:
                 assert np.array_equal(got.sci, pl.sci)
         else:
             nb.init_atomdata(dom.npad, dom.npad_local, dom.ntype, dom.type)
+            nb.set_atom_order(dom.nhome + dom.nhalo, dom.host.atom_order(), dom.host.cell_index())   # for copy_x_to_xq / add_f
             nb.upload_shiftvec(dom.shift_vec)
             nb.init_pairlist(dom.pl_local, abi.LOCAL)
             nb.init_pairlist(dom.pl_nonlocal, abi.NONLOCAL)

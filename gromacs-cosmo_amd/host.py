@@ -41,6 +41,7 @@ def _load():
     lib.nbnxn_host_copy_x_to_xq.argtypes = [vp, vp, vp]
     lib.nbnxn_host_add_f.argtypes = [vp, vp, ci, ci, vp]
     lib.nbnxn_host_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci, vp]
+    lib.nbnxn_host_make_pairlist_zones.argtypes = [vp, ci, ci, vp, cf, vp, vp, ci, vp]
     lib.nbnxn_host_pairlist.argtypes = [vp, ci]
     lib.nbnxn_host_pairlist.restype = C.POINTER(abi.Pairlist)
     lib.nbnxn_host_shift_vec.argtypes = [vp, vp]
@@ -152,12 +153,19 @@ class NbnxnHost:
         assert fnb.dtype == np.float32 and f.dtype == np.float32
         self._chk(self.lib.nbnxn_host_add_f(self.h, abi.ptr(fnb), a0, n, abi.ptr(f)))
 
-    def make_pairlist(self, iloc, rlist, xq, excl_index=None, excl_a=None, min_ci_balanced=0):
+    def make_pairlist(self, iloc, rlist, xq, excl_index=None, excl_a=None, min_ci_balanced=0, zone_pairs=None):
+        """zone_pairs: [(i-zone, first j-zone, end j-zone)], the reference's dd_zp tables (domdec.c:433-449); None = the
+        home zone against itself (LOCAL) or against every halo zone (NONLOCAL)."""
         if excl_index is not None:
             excl_index = np.ascontiguousarray(excl_index, dtype=np.int32)
             excl_a = np.ascontiguousarray(excl_a, dtype=np.int32)
-        self._chk(self.lib.nbnxn_host_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a),
-                                                     min_ci_balanced, abi.ptr(xq)))
+        if zone_pairs is None:
+            self._chk(self.lib.nbnxn_host_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a),
+                                                         min_ci_balanced, abi.ptr(xq)))
+        else:
+            zp = np.ascontiguousarray(zone_pairs, dtype=np.int32).reshape(-1, 3)
+            self._chk(self.lib.nbnxn_host_make_pairlist_zones(self.h, iloc, len(zp), abi.ptr(zp), rlist, abi.ptr(excl_index),
+                                                               abi.ptr(excl_a), min_ci_balanced, abi.ptr(xq)))
         v = self.lib.nbnxn_host_pairlist(self.h, iloc).contents
 
         def grab(addr, n, dt):

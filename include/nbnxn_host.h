@@ -88,6 +88,14 @@ int nbnxn_host_make_pairlist(nbnxn_host_ptr_t h, int iloc, float rlist,
                              const int *excl_index, const int *excl_a,
                              int min_ci_balanced, const float *xq);
 
+/* The same with the zone pairs of a domain decomposition: nzp triples {i-zone, first j-zone, end j-zone} as the
+ * reference's dd_zp3 / dd_zp2 / dd_zp1 (mdlib/domdec.c:433-449) give them to the i-zone loop of nbnxn_make_pairlist
+ * (nbnxn_search.c:5652-5699).  i-clusters of the list may then lie in halo zones (the eighth-shell decomposition
+ * computes pairs between two imported zones).  {0, 0, 1} is the local list, {0, 1, nzones} the non-local list of
+ * nbnxn_host_make_pairlist. */
+int nbnxn_host_make_pairlist_zones(nbnxn_host_ptr_t h, int iloc, int nzp, const int *zone_pairs, float rlist,
+                                   const int *excl_index, const int *excl_a, int min_ci_balanced, const float *xq);
+
 /* Progressive balancing of split lists (default on): entries get one of four pair budgets around the average
  * that min_ci_balanced implies, by a hash of (i super-cell, shift), so that the smallest entries -- which the
  * GPU runs last, the list being ordered by size -- are a third of the average (the reference's progBal,

@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims=(2,)):
+def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims=(2,), scheme="half"):
     import gromacs_cosmo_amd as g
     from gromacs_cosmo_amd import abi, dd
     import oracle as O
@@ -42,7 +42,7 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
         else:
             gr = grid or (1, 1, world)
             glob = g.system.water_box(2 * gr[0], 2 * gr[1], 2 * gr[2], model=model)
-        dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims)
+        dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims, scheme=scheme)
         xq_t = torch.from_numpy(dom.xq)                 # aliases dom.xq
         f_t = torch.zeros((dom.npad, 3), dtype=torch.float64)
         halo = dd.HaloExchange(dom, xq_t, f_t)
@@ -56,7 +56,7 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
         o_n = O.kernel_gpu_list(dom.xq, dom.type, dom.ntype, dom.nbfp, dom.shift_vec, dom.pl_nonlocal, ip)
         f_t += torch.from_numpy(np.asarray(o_l["f"], dtype=np.float64) + np.asarray(o_n["f"], dtype=np.float64))
         # non-local entries only touch home i-atoms and halo j-atoms
-        assert dom.pl_nonlocal.nsci > 0 and dom.pl_nonlocal.sci["sci"].max() * 64 < dom.npad_local
+        assert dom.pl_nonlocal.nsci > 0 and (scheme == "eighth" or dom.pl_nonlocal.sci["sci"].max() * 64 < dom.npad_local)
         halo.return_f()
         out = torch.zeros((abi.OUT_SLOTS, abi.OUT_STRIDE), dtype=torch.float64)
         out[0, 0] = o_l["Vvdw"] + o_n["Vvdw"]
@@ -86,7 +86,8 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
                          vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()),
                          nhome=dom.nhome, nhalo=dom.nhalo, natoms=glob.natoms,
                          nsci=(dom.pl_local.nsci, dom.pl_nonlocal.nsci), nmsg=len(dom.msgs), nzones=len(dom.zones),
-                         peers=sorted({m.recv_from for m in dom.msgs}))
+                         peers=sorted({m.recv_from for m in dom.msgs}),
+                         nonhome_i=int((dom.pl_nonlocal.sci["sci"] * 64 >= dom.npad_local).sum()))
     finally:
         dist.destroy_process_group()
 
@@ -127,6 +128,27 @@ def test_brick_decomposition_matches_single_domain(world, grid, self_dims, model
     for r in res:
         assert r["nmsg"] == {1: 1, 2: 4, 3: 13}[ncut] and r["nzones"] == r["nmsg"] + 1
         assert r["nhalo"] > 0 and r["nsci"][1] > 0
+        assert r["err"] < 2e-6, r
+        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
+        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r
+        assert r["vir_err"] < 1e-5, r
+
+
+# The reference's eighth shell (dd_zo / dd_zp3, domdec.c:432-449) with the same direct messages: 1 / 3 / 7 imported zones,
+# and pairs BETWEEN imported zones in the non-local list, whose i-clusters are then not all home clusters.
+@pytest.mark.parametrize("world,grid,self_dims,model,mcb", [
+    (4, (2, 2, 1), (), "spce", 0), (4, (1, 2, 2), (), "spc", 150), (8, (2, 2, 2), (), "spce", 0), (6, (3, 2, 1), (), "spc", 0),
+    (1, (1, 1, 1), (0, 1, 2), "spce", 0), (2, (1, 1, 2), (), "spc", 0)])
+def test_eighth_shell_decomposition_matches_single_domain(world, grid, self_dims, model, mcb):
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, _free_port(), model, mcb, ret, grid, self_dims, "eighth"), nprocs=world, join=True)
+        res = [ret[r] for r in range(world)]
+    assert sum(r["nhome"] for r in res) == res[0]["natoms"]
+    ncut = sum(1 for d in range(3) if grid[d] > 1 or (world == 1 and d in self_dims))
+    for r in res:
+        assert r["nmsg"] == {1: 1, 2: 3, 3: 7}[ncut] and r["nzones"] == r["nmsg"] + 1
+        assert (r["nonhome_i"] > 0) == (ncut > 1)        # zone x zone pairs exist from two cut dimensions on
         assert r["err"] < 2e-6, r
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 DEADLINE_S = 100
 
 
-def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_direct=False, grid=None, self_dims=(2,)):
+def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_direct=False, grid=None, self_dims=(2,), scheme="half"):
     import datetime
     import faulthandler
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -44,9 +44,9 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
         ip = g.system.reaction_field(0.9, rlist=1.0) if model == "spc" else g.system.ewald(0.9, rlist=1.0)
         tiles = (2, 2, 2)
         run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
-                         rccl_direct=rccl_direct, grid=grid, self_dims=self_dims)
+                         rccl_direct=rccl_direct, grid=grid, self_dims=self_dims, scheme=scheme)
         dom = run.dom
-        assert len(dom.msgs) == {1: 1, 2: 4, 3: 13}[sum(dom.decomp)]
+        assert len(dom.msgs) == ({1: 1, 2: 4, 3: 13} if scheme == "half" else {1: 1, 2: 3, 3: 7})[sum(dom.decomp)]
         # wreck the imported coordinates on the device: the step has to bring them back
         run.xq_t[run.halo.halo_slots, :3] = 1e6
         for _ in range(3):
@@ -179,6 +179,22 @@ def test_brickrun_one_rank_over_rccl(self_dims, rccl_direct):
     with mp.Manager() as m:
         ret = m.dict()
         _watch(mp.spawn(_worker, args=(1, _free_port(), "spce", True, ret, "nccl", rccl_direct, (1, 1, 1), self_dims), nprocs=1, join=False))
+        r = ret[0]
+    assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
+    assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
+    assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
+    assert r["vir_err"] < 1e-5, r
+
+
+@pytest.mark.parametrize("self_dims", [(0, 1, 2), (0, 1)])
+def test_eighth_shell_one_rank_over_rccl(self_dims):
+    """The reference's eighth shell (dd_zo / dd_zp3, domdec.c:432-449) on the GPU: 7 (3) imported zones on one rank that is
+    its own neighbour in three (two) dimensions, messages over RCCL issued by the module, and a NON-LOCAL list with
+    pairs between imported zones -- i-clusters that are not home clusters, as stock mdrun's search gives the kernel
+    under domain decomposition.  Lists from the host builder (the device search pairs home i-clusters only)."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_worker, args=(1, _free_port(), "spce", True, ret, "nccl", True, (1, 1, 1), self_dims, "eighth"), nprocs=1, join=False))
         r = ret[0]
     assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
     assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
