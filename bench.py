@@ -300,8 +300,9 @@ def main():
     ap.add_argument("--precondition", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up steps, so that the timed region runs at the clock the GPU sustains")
     ap.add_argument("--dd-grid", default="", help="ranks along x,y,z (default 1,1,N: z slabs); e.g. 2,2,2 for --gpus 8")
-    ap.add_argument("--dd-scheme", default="half", choices=["half", "eighth"],
-                    help="half shell with home i-clusters only (default) or the reference's eighth shell with pairs between imported zones")
+    ap.add_argument("--dd-scheme", default="auto", choices=["auto", "half", "eighth"],
+                    help="half shell with home i-clusters only, or the reference's eighth shell with pairs between imported zones; "
+                         "auto: the eighth shell when three dimensions are cut (7 messages instead of 13), else the half shell")
     ap.add_argument("--dd-self-dims", default="2", help="with --dd-self: the dimensions the one rank is its own neighbour in (0,1,2 = the 13-message step)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --tiles is the whole box, cut into --gpus slabs (default: --tiles per GPU)")
@@ -392,6 +393,9 @@ def main():
         rccl_direct = not rehearsal and os.environ.get("BENCH_DD_TORCH") != "1"
         grid = tuple(int(v) for v in args.dd_grid.split(",")) if args.dd_grid else (1, 1, world)
         self_dims = tuple(int(v) for v in args.dd_self_dims.split(",")) if args.dd_self else ()
+        ncut = sum(1 for d in range(3) if grid[d] > 1 or d in self_dims)
+        if args.dd_scheme == "auto":
+            args.dd_scheme = "eighth" if ncut == 3 else "half"
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong, grid=grid,
                          self_dims=self_dims, scheme=args.dd_scheme)
         rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module

@@ -17,7 +17,8 @@ halo f).  The path's multi-GPU form here has the same data flow with a simpler z
     forward corner data through intermediate ranks (domdec.c:667-758) and computes zone x zone pairs; on a node
     whose 8 GPUs are all linked to each other every neighbour is one hop away, the faces carry nearly all of the
     volume in both schemes (13x13x14 tiles on 2x2x2 ranks: 28 % of the home atoms here, 26 % there), and one grouped
-    RCCL call moves all messages at once.  Bricks must be thicker than rlist so that only neighbours interact;
+    RCCL call moves all messages at once.  Measured on one rank that is its own neighbour: a tie with two cut dimensions,
+    the eighth shell 21 % faster with three (7 messages and zones instead of 13): see scheme="eighth" below.  Bricks must be thicker than rlist so that only neighbours interact;
   * scheme="eighth" is the reference's own zone scheme with the same direct messages: the 1 / 3 / 7 zones of dd_zo, and the
     zone pairs of dd_zp1 / dd_zp2 / dd_zp3 in the lists, so the non-local list also holds pairs BETWEEN imported zones and its
     i-clusters are not all home clusters (what stock mdrun's search hands the kernel under domain decomposition).  The host
