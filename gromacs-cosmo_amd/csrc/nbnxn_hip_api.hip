@@ -1467,7 +1467,14 @@ int nbnxn_hip_put_on_grid(nbnxn_hip_ptr_t nb, const float box[9], const int pbc_
 
 int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced)
 {
+    return nbnxn_hip_make_pairlist_zones(nb, iloc, 0, nullptr, rlist, excl_index, excl_a, min_ci_balanced);
+}
+
+int nbnxn_hip_make_pairlist_zones(nbnxn_hip_ptr_t nb, int iloc, int nzp, const int *zone_pairs, float rlist, const int *excl_index,
+                                  const int *excl_a, int min_ci_balanced)
+{
     if (check_handle(nb)) { return 1; }
+    if (nzp < 0 || (nzp > 0 && !zone_pairs)) { return nbx_fail("make_pairlist: %d zone pairs without a table", nzp); }
     if (check_loc(iloc)) { return 1; }
     if (iloc == NBX_NONLOCAL && nb->search && nbx_search_nzones(nb->search) < 2) { return nbx_fail("a non-local list needs halo zones on the grid (nbnxn_hip_put_on_grid_zones)"); }
     if (!nb->search || !nb->grid_on_device || nbx_search_natoms_padded(nb->search) != nb->natoms) { return nbx_fail("make_pairlist before put_on_grid (or after a new init_atomdata)"); }
@@ -1491,7 +1498,7 @@ int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int
         nb->excl_held = true;
     }
     nbx_search_list_t L;
-    if (nbx_search_make_pairlist(nb->search, st, iloc, rlist, min_ci_balanced, d_ei, d_ea, nb->xq.p, &L))
+    if (nbx_search_make_pairlist(nb->search, st, iloc, nzp, zone_pairs, rlist, min_ci_balanced, d_ei, d_ea, nb->xq.p, &L))
     {
         return nbx_fail("make_pairlist: %s", nbx_search_error());
     }

@@ -46,8 +46,10 @@ struct nbx_search_list_t {
 // nbnxn_make_pairlist (nbnxn_search.c:5583): iloc NBX_LOCAL = home zone against itself (half list), NBX_NONLOCAL =
 // home zone against the halo zones (all shifts); the list in the GPU format, left on the device until the next call.
 // d_excl_index [atoms+1] / d_excl_a: topology exclusions (t_blocka) in caller numbering, may be null.
-int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlist, int min_ci_balanced, const int *d_excl_index,
-                             const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out);
+// zone_pairs [3 * nzp] = {i-zone, first j-zone, end j-zone} (host memory), the reference's dd_zp tables
+// (domdec.c:433-449, the i-zone loop of nbnxn_make_pairlist, nbnxn_search.c:5652-5699); nzp = 0: the pairs above.
+int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, int nzp, const int *zone_pairs, float rlist, int min_ci_balanced,
+                             const int *d_excl_index, const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out);
 
 // verification: grid geometry and per-cluster data back on the host
 int nbx_search_grid_info(const nbx_search *s, int zone, int *ncx, int *ncy, int *nc);

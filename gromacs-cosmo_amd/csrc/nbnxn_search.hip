@@ -86,11 +86,15 @@ struct ZoneParams {
     const int *cxy_ind;   // column -> first super-cell, zone-local numbering
     int        cell0;     // first super-cell of the zone in the global numbering
     int        zr;        // index of the zone's z-range in zrange[]
-    float      rbb2;      // boundingbox_only_distance2 of (i-zone, this zone)
 };
 
+constexpr int MAX_IZONES = 4;   // i-zones of a list: the reference's zone pairs have at most four (dd_zp3, domdec.c:440)
+
 struct ListParams {
-    int        nci;       // super-cells of the i-zone (the home zone, cell0 = 0)
+    int        nci;       // super-cells of the i-zones (zones 0 .. niz - 1, contiguous from cell 0; the home zone alone unless zone pairs say more)
+    int        iz_end[MAX_IZONES];      // first super-cell behind i-zone k
+    unsigned   allowed[MAX_IZONES];     // bit j: i-zone k is paired with the list's j-zone slot j
+    float      rbb2[MAX_IZONES][MAX_ZONES];   // boundingbox_only_distance2 of (i-zone, j-zone slot)
     int        njz;       // j-zones of this list: 1 (the home zone itself) or the halo zones
     int        same;      // the j-zone is the i-zone: half list, 14 shifts; otherwise all 27 shifts
     int        wide;      // a skewed box that needs two box lengths in x (shp[0] == 2): 23 / 45 shifts instead
@@ -435,7 +439,10 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
     const int *__restrict__ cxy_ind = Z.cxy_ind;
     const int   cell0 = Z.cell0;          // j super-cells: zone-local index + cell0 = global index
     const int nsub_i = nsubc[sci];
-    const bool active = nsub_i > 0 && abs(tx) <= P.shp[0] && abs(ty) <= P.shp[1] && abs(tz) <= P.shp[2];
+    int       iz     = 0;                 // the i-zone of this super-cell
+    while (iz < MAX_IZONES - 1 && sci >= P.iz_end[iz]) { iz++; }
+    const float rbb2_iz = P.rbb2[iz][en.jzi];
+    const bool  active  = nsub_i > 0 && abs(tx) <= P.shp[0] && abs(ty) <= P.shp[1] && abs(tz) <= P.shp[2] && ((P.allowed[iz] >> en.jzi) & 1u);
     if (!active)
     {
         if (!FILL && lane == 0) { ncj[e] = 0; }
@@ -565,7 +572,7 @@ k_list(ListParams P, const int *__restrict__ nsubc, const float *__restrict__ bb
                             if (d2c < P.rl2) { mb |= 1u << ci; ci_last = ci; d2_last = d2c; np++; }
                         }
                         // a lone cluster pair beyond the box-only radius gets the atom check (:3073-3092)
-                        if (np == 1 && d2_last >= Z.rbb2)
+                        if (np == 1 && d2_last >= rbb2_iz)
                         {
                             // all eight j-atoms are requested at once (a loop with an early exit would wait for
                             // them one by one); "any pair in range" does not depend on the order of the tests
@@ -1172,8 +1179,8 @@ int nsubpair_max(const nbx_search &s, float rlist, int min_ci_balanced, double f
 
 } // namespace
 
-int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlist, int min_ci_balanced, const int *d_excl_index,
-                             const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out)
+int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, int nzp, const int *zone_pairs, float rlist, int min_ci_balanced,
+                             const int *d_excl_index, const int *d_excl_a, const float4 *d_xq, nbx_search_list_t *out)
 {
     if (!s || s->nzones == 0 || s->nzones_filled != s->nzones) { return sfail("no grid: put the atoms on the grid first"); }
     if (!(rlist > 0)) { return sfail("rlist must be > 0"); }
@@ -1196,12 +1203,49 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
     {
         return sfail("box[YY][YY] - |box[ZZ][YY]| = %g is shorter than rlist = %g", s->box[1] - std::fabs(s->bzy), rlist);
     }
-    const Zone &zi = s->zone[0];
     ListParams  P;
     memset(&P, 0, sizeof(P));
-    P.nci  = zi.nc;
     P.same = same ? 1 : 0;
     P.njz  = same ? 1 : s->nzones - 1;
+    // Which i-zones meet which j-zone slots.  Without zone pairs: the home zone against itself (local) or against
+    // every halo zone (non-local).  With them (the reference's dd_zp tables, domdec.c:433-449, as the host builder
+    // takes them): the local list is {0, 0, 1}; in the non-local list i-zones 0 .. 3 meet halo zones only, never
+    // their own, so no pair of that list is within one grid and every entry visits all shifts.
+    int niz = 1;
+    if (nzp <= 0 || !zone_pairs)
+    {
+        P.allowed[0] = same ? 1u : ((1u << (s->nzones - 1)) - 1u);
+    }
+    else
+    {
+        for (int z = 0; z < nzp; z++)
+        {
+            const int iz = zone_pairs[3 * z], j0 = zone_pairs[3 * z + 1], j1 = zone_pairs[3 * z + 2];
+            if (iz < 0 || iz >= s->nzones || j0 < 0 || j1 > s->nzones || j0 > j1)
+            {
+                return sfail("zone pair %d = {%d, %d, %d} outside the %d gridded zones", z, iz, j0, j1, s->nzones);
+            }
+            if (same)
+            {
+                if (nzp != 1 || iz != 0 || j0 != 0 || j1 != 1) { return sfail("the local list is the zone pair {0, 0, 1}"); }
+                P.allowed[0] = 1u;
+                continue;
+            }
+            if (iz >= MAX_IZONES) { return sfail("zone pair %d: i-zone %d, at most %d i-zones", z, iz, MAX_IZONES); }
+            if (j1 > j0 && (j0 < 1 || (iz >= j0 && iz < j1)))
+            {
+                return sfail("zone pair %d = {%d, %d, %d}: the non-local list pairs i-zones with other halo zones only", z, iz, j0, j1);
+            }
+            for (int j = j0; j < j1; j++) { P.allowed[iz] |= 1u << (j - 1); }
+            if (j1 > j0) { niz = std::max(niz, iz + 1); }
+        }
+    }
+    for (int k = 0; k < MAX_IZONES; k++)
+    {
+        const int zk = std::min(k, niz - 1);
+        P.iz_end[k]  = s->zone[zk].cell0 + s->zone[zk].nc;
+    }
+    P.nci = P.iz_end[niz - 1];
     for (int d = 0; d < 3; d++) { P.box[d] = s->box[d]; P.shp[d] = s->shp[d]; }
     P.byx = s->byx; P.bzx = s->bzx; P.bzy = s->bzy;
     // shift range (nbnxn_search.c:4906-4927): a skewed box can need two box lengths in x
@@ -1216,12 +1260,16 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, float rlis
         const Zone &zj  = s->zone[zid];
         ZoneParams &zp  = P.zp[k];
         zp.g = zj.g; zp.cxy_ind = zj.cxy_ind.p; zp.cell0 = zj.cell0; zp.zr = zid;
-        // boundingbox_only_distance2 (:4721-4757), float arithmetic as in the host builder
-        const float bbx = 0.5f * (zi.g.sx + zj.g.sx) / 2, bby = 0.5f * (zi.g.sy + zj.g.sy) / 2;
-        const float r   = std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby));
-        zp.rbb2 = r * r;
+        for (int iz = 0; iz < niz; iz++)
+        {
+            // boundingbox_only_distance2 (:4721-4757), float arithmetic as in the host builder
+            const Zone &zi  = s->zone[iz];
+            const float bbx = 0.5f * (zi.g.sx + zj.g.sx) / 2, bby = 0.5f * (zi.g.sy + zj.g.sy) / 2;
+            const float r   = std::max(0.0f, rlist - 0.5f * std::sqrt(bbx * bbx + bby * bby));
+            P.rbb2[iz][k]   = r * r;
+        }
     }
-    const int nent = zi.nc * entries_per_cell(em);
+    const int nent = P.nci * entries_per_cell(em);
     int      *cnt  = s->counters.p;   // [2 + z] clusters with atoms of zone z, [20] scratch overflow flag
 
     if (s->ncj.reserve(nent + 1) || s->ncj4_e.reserve(nent + 1) || s->cj4_start.reserve(nent + 1) || s->nparts.reserve(nent + 1)

@@ -22,7 +22,7 @@ halo f).  The path's multi-GPU form here has the same data flow with a simpler z
   * scheme="eighth" is the reference's own zone scheme with the same direct messages: the 1 / 3 / 7 zones of dd_zo, and the
     zone pairs of dd_zp1 / dd_zp2 / dd_zp3 in the lists, so the non-local list also holds pairs BETWEEN imported zones and its
     i-clusters are not all home clusters (what stock mdrun's search hands the kernel under domain decomposition).  The host
-    builder makes those lists (nbnxn_host_make_pairlist_zones); the device search pairs home i-clusters only;
+    builder (nbnxn_host_make_pairlist_zones) and the device search (nbnxn_hip_make_pairlist_zones) make the same lists;
   * per step: halo coordinates travel to the ranks that import them (plus the box vectors of the periodic
     boundaries they cross), halo forces travel back and are added to the owner's forces -- those that crossed a
     boundary also to the shift force of that crossing, the rule of dd_move_f (domdec.c:837-851); {e_lj, e_el,
@@ -150,6 +150,7 @@ class Domain:
     rlist: float = 0.0
     min_ci_balanced: int = 0
     scheme: str = "half"     # "half": half shell, home i-clusters only; "eighth": the reference's zones and zone pairs
+    zone_pairs: tuple = (None, None)   # (local, non-local) rows {i-zone, first j-zone, end j-zone}; None = home i-clusters only
 
     @property
     def pair_slots(self):
@@ -343,7 +344,8 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
                   npad=len(xq), npad_local=host.natoms_padded_local, msgs=msgs,
                   send_slots=send_slots, halo_slots=cell[nhome:nhome + nhalo].astype(np.int64),
                   zones=zones, x_all=x_all, type_all=glob.type[ids_all].astype(np.int32), q_all=glob.q[ids_all].astype(np.float32),
-                  excl_index=excl_index, excl_a=excl_a, rlist=float(ip.rlist), min_ci_balanced=int(min_ci_balanced), scheme=scheme)
+                  excl_index=excl_index, excl_a=excl_a, rlist=float(ip.rlist), min_ci_balanced=int(min_ci_balanced), scheme=scheme,
+                  zone_pairs=(zp_local, zp_nonlocal))
 
 
 class _Layout:
@@ -546,8 +548,6 @@ class SlabRun:
             if verbose:
                 print(f"[dd rank {rank}] {_time.perf_counter() - _t0:6.1f} s  {what}", file=sys.stderr, flush=True)
         self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims, scheme=scheme)
-        if scheme == "eighth":
-            device_search = False      # the device search pairs home i-clusters only: the eighth shell's lists come from the host builder
         say(f"domain built: {dom.nhome} home + {dom.nhalo} halo atoms, lists {dom.pl_local.nsci} / {dom.pl_nonlocal.nsci} entries")
         nb.init_const(ip, dom.ntype, dom.nbfp)
         if device_search:
@@ -555,9 +555,9 @@ class SlabRun:
             # halo bookkeeping above came from, double as the check that both see the same grid
             npad = nb.put_on_grid_zones(dom.box_search, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=dom.pbc_shift_dim)
             assert npad == dom.npad
-            nb.make_pairlist(dom.rlist, dom.excl_index, dom.excl_a, dom.min_ci_balanced, iloc=abi.LOCAL)
+            nb.make_pairlist(dom.rlist, dom.excl_index, dom.excl_a, dom.min_ci_balanced, iloc=abi.LOCAL, zone_pairs=dom.zone_pairs[0])
             if len(dom.zones) > 1:
-                nb.make_pairlist(dom.rlist, None, None, dom.min_ci_balanced, iloc=abi.NONLOCAL)
+                nb.make_pairlist(dom.rlist, None, None, dom.min_ci_balanced, iloc=abi.NONLOCAL, zone_pairs=dom.zone_pairs[1])
             for iloc, pl in ((abi.LOCAL, dom.pl_local), (abi.NONLOCAL, dom.pl_nonlocal))[:len(dom.zones)]:
                 got = nb.download_pairlist(iloc)
                 assert (got.nsci, got.ncj4, got.nexcl, got.nci_tot) == (pl.nsci, pl.ncj4, pl.nexcl, pl.nci_tot)

@@ -104,6 +104,7 @@ def load():
     lib.nbnxn_hip_put_on_grid.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, cf]
     lib.nbnxn_hip_put_on_grid_zones.argtypes = [vp, vp, vp, ci, C.POINTER(abi.GridZone), ci, vp, ci, vp, vp]
     lib.nbnxn_hip_make_pairlist.argtypes = [vp, ci, cf, vp, vp, ci]
+    lib.nbnxn_hip_make_pairlist_zones.argtypes = [vp, ci, ci, vp, cf, vp, vp, ci]
     lib.nbnxn_hip_forget_exclusions.argtypes = [vp]
     lib.nbnxn_hip_set_progressive_balance.argtypes = [vp, ci]
     lib.nbnxn_hip_download_grid.argtypes = [vp] + [vp] * 8
@@ -256,11 +257,17 @@ class NbnxnHip:
         self.natoms_real = n
         return self.natoms
 
-    def make_pairlist(self, rlist, excl_index=None, excl_a=None, min_ci_balanced=0, iloc=abi.LOCAL):
+    def make_pairlist(self, rlist, excl_index=None, excl_a=None, min_ci_balanced=0, iloc=abi.LOCAL, zone_pairs=None):
+        """zone_pairs: rows {i-zone, first j-zone, end j-zone} of the reference's dd_zp tables (eighth shell), or None."""
         if excl_index is not None:
             excl_index = np.ascontiguousarray(excl_index, dtype=np.int32)
             excl_a = np.ascontiguousarray(excl_a, dtype=np.int32)
-        self._chk(self.lib.nbnxn_hip_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a), min_ci_balanced))
+        if zone_pairs is None:
+            self._chk(self.lib.nbnxn_hip_make_pairlist(self.h, iloc, rlist, abi.ptr(excl_index), abi.ptr(excl_a), min_ci_balanced))
+        else:
+            zp = np.ascontiguousarray(zone_pairs, dtype=np.int32).reshape(-1, 3)
+            self._chk(self.lib.nbnxn_hip_make_pairlist_zones(self.h, iloc, len(zp), abi.ptr(zp), rlist, abi.ptr(excl_index),
+                                                             abi.ptr(excl_a), min_ci_balanced))
 
     def set_progressive_balance(self, on):
         self._chk(self.lib.nbnxn_hip_set_progressive_balance(self.h, int(on)))

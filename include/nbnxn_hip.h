@@ -489,6 +489,13 @@ int nbnxn_hip_put_on_grid_zones(nbnxn_hip_ptr_t nb, const float box[9], const in
  * home zone against itself; NBX_NONLOCAL: the home zone against the halo zones given to
  * nbnxn_hip_put_on_grid_zones (nbnxn_search.c:5652-5699). */
 int nbnxn_hip_make_pairlist(nbnxn_hip_ptr_t nb, int iloc, float rlist, const int *excl_index, const int *excl_a, int min_ci_balanced);
+/* The same with the zone pairs of the reference's eighth shell: zone_pairs [3 * nzp] = {i-zone, first j-zone,
+ * end j-zone}, the dd_zp1 / dd_zp2 / dd_zp3 tables (domdec.c:433-449) that nbnxn_make_pairlist walks in its i-zone
+ * loop (nbnxn_search.c:5652-5699).  The local list is {0, 0, 1}; the non-local list pairs up to four i-zones
+ * (imported ones included) with halo zones other than their own.  Same lists as nbnxn_host_make_pairlist_zones
+ * (include/nbnxn_host.h).  nzp = 0 is nbnxn_hip_make_pairlist. */
+int nbnxn_hip_make_pairlist_zones(nbnxn_hip_ptr_t nb, int iloc, int nzp, const int *zone_pairs, float rlist, const int *excl_index,
+                                  const int *excl_a, int min_ci_balanced);
 int nbnxn_hip_forget_exclusions(nbnxn_hip_ptr_t nb);
 /* Progressive balancing of the lists nbnxn_hip_make_pairlist splits (default on), the device builder's
  * side of nbnxn_host_set_progressive_balance (include/nbnxn_host.h): same rule, same lists. */

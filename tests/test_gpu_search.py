@@ -410,6 +410,41 @@ def test_device_search_with_a_halo_zone(nb, kind, rank):
         assert np.array_equal(got, want) and (want != pl_n.cj4["imei"]["imask"]).any()
 
 
+@pytest.mark.parametrize("self_dims", [(2,), (1, 2), (0, 2), (0, 1, 2)])
+def test_device_search_with_zone_pairs(nb, self_dims, grid=(1, 1, 1), rank=0):
+    """the reference's eighth shell (dd_zo / dd_zp1-3, domdec.c:433-449): 1 / 3 / 7 imported zones, the non-local list
+    with imported i-clusters; the device search makes the host builder's lists, whole arrays"""
+    import tempfile
+    import torch.distributed as dist
+    from gromacs_cosmo_amd import dd
+    glob, ip = g.system.water_box(3, 3, 3, model="spce"), g.system.ewald(0.9, rlist=1.0)
+    world = grid[0] * grid[1] * grid[2]
+    # build_domain sends the halo bookkeeping through torch.distributed, also to itself
+    with tempfile.TemporaryDirectory() as tmp:
+        dist.init_process_group("gloo", init_method=f"file://{tmp}/store", rank=rank, world_size=world)
+        try:
+            dom = dd.build_domain(glob, ip, rank, world, "cpu", 600, grid=grid, self_dims=self_dims, scheme="eighth")
+        finally:
+            dist.destroy_process_group()
+    ndim = sum(dom.decomp)
+    assert len(dom.zones) == 2 ** ndim and dom.zone_pairs[1] == dd.eighth_shell_zone_pairs(ndim)[1]
+    nb.init_const(ip, dom.ntype, dom.nbfp)
+    nb.forget_exclusions()
+    npad = nb.put_on_grid_zones(dom.box_search, dom.zones, dom.x_all, dom.type_all, dom.q_all, pbc_shift_dim=dom.pbc_shift_dim)
+    assert npad == dom.npad
+    nb.make_pairlist(dom.rlist, dom.excl_index, dom.excl_a, dom.min_ci_balanced, iloc=abi.LOCAL, zone_pairs=dom.zone_pairs[0])
+    nb.make_pairlist(dom.rlist, None, None, dom.min_ci_balanced, iloc=abi.NONLOCAL, zone_pairs=dom.zone_pairs[1])
+    _assert_same_list(nb.download_pairlist(abi.LOCAL), dom.pl_local)
+    _assert_same_list(nb.download_pairlist(abi.NONLOCAL), dom.pl_nonlocal)
+    if ndim > 1:
+        # i-clusters of imported zones are in the list
+        assert dom.pl_nonlocal.sci["sci"].max() * 64 >= dom.npad_local
+    # tables the device search does not take
+    for iloc, zp in ((abi.LOCAL, ((0, 0, 2),)), (abi.NONLOCAL, ((1, 1, 2),)), (abi.NONLOCAL, ((0, 0, 2),)), (abi.NONLOCAL, ((0, 1, 99),))):
+        with pytest.raises(g.gpu.HipError):
+            nb.make_pairlist(dom.rlist, None, None, dom.min_ci_balanced, iloc=iloc, zone_pairs=zp)
+
+
 def test_device_search_at_config4_size(nb):
     """1,533,168 atoms (BASELINE config 4): the device grid and list against the host builder's, whole arrays"""
     s = g.system.water_box(13, 13, 14)
