@@ -304,6 +304,10 @@ def main():
                     help="half shell with home i-clusters only, or the reference's eighth shell with pairs between imported zones; "
                          "auto: the eighth shell when three dimensions are cut (7 messages instead of 13), else the half shell")
     ap.add_argument("--dd-self-dims", default="2", help="with --dd-self: the dimensions the one rank is its own neighbour in (0,1,2 = the 13-message step)")
+    ap.add_argument("--dd-film", default="", help="liquid_fraction,vapour_keep: a liquid film under thin vapour instead of the full box "
+                                                  "(a density step along z, the workload load balancing is for); not the headline workload")
+    ap.add_argument("--dd-balance", type=int, default=0,
+                    help="iterations of the reference's load-balancing rule (domdec.c:3429) on the ranks' cluster-pair counts before the run")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --tiles is the whole box, cut into --gpus slabs (default: --tiles per GPU)")
     args = ap.parse_args()
@@ -397,7 +401,8 @@ def main():
         if args.dd_scheme == "auto":
             args.dd_scheme = "eighth" if ncut == 3 else "half"
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong, grid=grid,
-                         self_dims=self_dims, scheme=args.dd_scheme)
+                         self_dims=self_dims, scheme=args.dd_scheme, balance=args.dd_balance,
+                         film=(lambda v: (float(v[0]), int(v[1])))(args.dd_film.split(",")) if args.dd_film else None)
         rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global

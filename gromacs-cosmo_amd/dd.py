@@ -151,6 +151,7 @@ class Domain:
     min_ci_balanced: int = 0
     scheme: str = "half"     # "half": half shell, home i-clusters only; "eighth": the reference's zones and zone pairs
     zone_pairs: tuple = (None, None)   # (local, non-local) rows {i-zone, first j-zone, end j-zone}; None = home i-clusters only
+    balance_history: list = None       # balance_domain: max/mean - 1 of the ranks' cluster-pair counts, per iteration
 
     @property
     def pair_slots(self):
@@ -206,10 +207,92 @@ def _exchange_split(send, in_splits, recv, out_splits):
     dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits)
 
 
-def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,), scheme="half"):
+def uniform_cuts(grid):
+    """cell boundaries as fractions of the box, per dimension: equal bricks"""
+    return tuple(np.linspace(0.0, 1.0, int(grid[d]) + 1) for d in range(3))
+
+
+DD_CELL_MARGIN = 1.0001     # domdec.c:452
+DLB_RELAX = 0.5             # set_dd_cell_sizes_dlb_root, domdec.c:3440
+DLB_CHANGE_LIMIT = 0.10     # comm->dlb_scale_lim = 10 %, domdec.c:6654 (GMX_DLB_MAX_BOX_SCALING)
+
+
+def dlb_update_cuts(cuts, grid, rank_loads, min_frac, relax=DLB_RELAX, change_limit=DLB_CHANGE_LIMIT):
+    """One step of the reference's dynamic load balancing (set_dd_cell_sizes_dlb_root, domdec.c:3467-3498, and the
+    limits of dd_cell_sizes_dlb_root_enforce_limits, :3221-3300) on a rectilinear grid: along every cut dimension the
+    load of a row of cells is the sum over the ranks in it; a cell's thickness changes by -relax * (its relative
+    imbalance), all cells of the row scaled down together when the largest change would exceed change_limit; no cell
+    gets thinner than min_frac[d] of the box, the others share what is left.  rank_loads: one number per rank (here
+    cluster pairs of its two lists, what the kernel's time is proportional to; the reference takes measured force
+    time, with a GPU the time waited for it, sim_util.c:1514-1518).  The reference staggers the boundaries of the
+    later dimensions per row of the earlier ones; this grid keeps them straight, so every face is still shared by
+    exactly two bricks and the direct messages stay as they are."""
+    loads = np.asarray(rank_loads, dtype=np.float64).reshape(int(grid[2]), int(grid[1]), int(grid[0]))   # rank_of order
+    new = []
+    for d in range(3):
+        n = int(grid[d])
+        old = np.asarray(cuts[d], dtype=np.float64)
+        if n == 1:
+            new.append(old.copy())
+            continue
+        row = loads.sum(axis=tuple(a for a in range(3) if a != 2 - d))
+        aver = row.sum() / n
+        imbalance = (row - aver) / (aver if aver > 0 else 1.0)
+        change_max = np.abs(relax * imbalance).max()
+        sc = relax * (change_limit / change_max if change_max > change_limit else 1.0)
+        size = (old[1:] - old[:-1]) * (1.0 - sc * imbalance)
+        minf = float(min_frac[d])
+        if n * minf > 1.0:
+            raise ValueError(f"{n} cells of at least {minf:.4f} of the box do not fit along {'xyz'[d]}")
+        fixed = np.zeros(n, dtype=bool)
+        while True:
+            free = ~fixed
+            scale = (1.0 - fixed.sum() * minf) / size[free].sum()
+            out = np.where(fixed, minf, size * scale)
+            below = free & (out < minf)
+            if not below.any():
+                break
+            fixed |= below
+        b = np.concatenate([[0.0], np.cumsum(out)])
+        b[-1] = 1.0
+        new.append(b)
+    return tuple(new)
+
+
+def balance_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,), scheme="half", iterations=24,
+                   tolerance=0.02):
+    """Static use of the reference's load-balancing rule: build the domains, gather every rank's cluster-pair count,
+    move the cut planes (dlb_update_cuts), repeat; keeps the cut with the smallest maximum.  Every rank computes the
+    same planes from the same gathered numbers.  Returns (Domain, history of max/mean - 1 per iteration)."""
+    grid = (1, 1, world) if grid is None else tuple(int(v) for v in grid)
+    box = np.asarray(glob.box, dtype=np.float64)
+    box = np.diag(box) if box.shape == (3, 3) else box
+    min_frac = [float(ip.rlist) * DD_CELL_MARGIN * 1.001 / float(box[d]) for d in range(3)]
+    cuts, best, history = uniform_cuts(grid), None, []
+    for it in range(iterations + 1):
+        dom = build_domain(glob, ip, rank, world, device, min_ci_balanced, grid=grid, self_dims=self_dims, scheme=scheme, cuts=cuts)
+        mine = torch.tensor([dom.pl_local.nci_tot + dom.pl_nonlocal.nci_tot], dtype=torch.int64)
+        if dist.get_backend() != "gloo":
+            mine = mine.to(device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        loads = np.array([int(p.item()) for p in parts], dtype=np.float64)
+        history.append(float(loads.max() / loads.mean() - 1.0))
+        if best is None or loads.max() < best[0]:
+            best = (loads.max(), dom)
+        if it == iterations or history[-1] < tolerance or world == 1:
+            break
+        cuts = dlb_update_cuts(cuts, grid, loads, min_frac)
+    dom = best[1]
+    dom.balance_history = history
+    return dom, history
+
+
+def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,), scheme="half", cuts=None):
     """Cuts rank `rank`'s brick out of the global system `glob` (every rank holds the synthetic
     global topology; coordinates of imported atoms still arrive by message, as they would in a
-    run), grids home and halo zones, and builds both lists.  grid = ranks along (x, y, z), default z slabs."""
+    run), grids home and halo zones, and builds both lists.  grid = ranks along (x, y, z), default z slabs.
+    cuts: per dimension the cell boundaries as fractions of the box (uniform_cuts / dlb_update_cuts); None = equal bricks."""
     if world < 1:
         raise ValueError("domain decomposition needs at least one rank")
     grid = (1, 1, world) if grid is None else tuple(int(v) for v in grid)
@@ -229,19 +312,33 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
         box = np.ascontiguousarray(np.diag(box_search))
     else:
         box = box_search
-    ext = np.array([float(box[d]) / grid[d] for d in range(3)])
+    me = coords_of(rank, grid)
+    if cuts is None:
+        ext = np.array([float(box[d]) / grid[d] for d in range(3)])
+        cell3 = [np.clip(np.floor(glob.x[:, d].astype(np.float64) / ext[d]).astype(np.int64), 0, grid[d] - 1) for d in range(3)]
+        lo = np.array([me[d] * ext[d] for d in range(3)])
+        hi = lo + ext
+        thinnest = ext
+    else:
+        # cut planes moved by the load balancing: the same planes for every row of cells (a rectilinear grid)
+        bnd = []
+        for d in range(3):
+            b = np.asarray(cuts[d], dtype=np.float64)
+            if b.shape != (grid[d] + 1,) or b[0] != 0.0 or b[-1] != 1.0 or not (np.diff(b) > 0).all():
+                raise ValueError(f"cuts along {'xyz'[d]} must be {grid[d] + 1} increasing fractions from 0 to 1")
+            bnd.append(b * float(box[d]))
+        cell3 = [np.clip(np.searchsorted(bnd[d], glob.x[:, d].astype(np.float64), side="right") - 1, 0, grid[d] - 1) for d in range(3)]
+        lo = np.array([bnd[d][me[d]] for d in range(3)])
+        hi = np.array([bnd[d][me[d] + 1] for d in range(3)])
+        thinnest = np.array([np.diff(bnd[d]).min() for d in range(3)])
     for d in range(3):
         # one rank is its own neighbour: periodic through a halo of its own atoms, which needs room for both
-        if decomp[d] and ext[d] <= ip.rlist * (2 if grid[d] == 1 else 1):
-            raise ValueError(f"brick thickness {ext[d]:.3f} nm along {'xyz'[d]} must exceed {'2 x ' if grid[d] == 1 else ''}rlist {ip.rlist:.3f} nm")
-    me = coords_of(rank, grid)
-    cell3 = [np.clip(np.floor(glob.x[:, d].astype(np.float64) / ext[d]).astype(np.int64), 0, grid[d] - 1) for d in range(3)]
+        if decomp[d] and thinnest[d] <= ip.rlist * (2 if grid[d] == 1 else 1):
+            raise ValueError(f"brick thickness {thinnest[d]:.3f} nm along {'xyz'[d]} must exceed {'2 x ' if grid[d] == 1 else ''}rlist {ip.rlist:.3f} nm")
     owner = (cell3[2] * grid[1] + cell3[1]) * grid[0] + cell3[0]
     home_ids = np.nonzero(owner == rank)[0]
     nhome = len(home_ids)
     x_home = glob.x[home_ids]
-    lo = np.array([me[d] * ext[d] for d in range(3)])
-    hi = lo + ext
     rl = np.float32(ip.rlist)
 
     msgs, sels, halo_id_parts, halo_x_parts = [], [], [], []
@@ -527,8 +624,10 @@ class SlabRun:
     (strong scaling, BASELINE configs[3]) cut into grid = (nx, ny, nz) bricks of equal size, default `world` z slabs."""
 
     def __init__(self, tiles, model, ip, rank, world, local_rank, flags, min_ci_balanced=None, device_search=True,
-                 device_halo=True, rccl_direct=False, strong=False, grid=None, self_dims=(2,), scheme="half"):
-        """device_halo: halo buffers packed by the module's kernels (else torch indexing operations), messages
+                 device_halo=True, rccl_direct=False, strong=False, grid=None, self_dims=(2,), scheme="half", balance=0, film=None):
+        """balance: iterations of the reference's load-balancing rule on the ranks' cluster-pair counts before the run
+        (balance_domain; 0 = equal bricks).  film = (liquid_fraction, vapour_keep): system.water_film instead of the full
+        box, the workload that needs it.  device_halo: halo buffers packed by the module's kernels (else torch indexing operations), messages
         through torch.distributed.  rccl_direct: everything, messages included, issued by the module on its own
         RCCL communicator (needs one GPU per rank)."""
         from . import gpu
@@ -536,7 +635,9 @@ class SlabRun:
         self.dev = torch.device("cuda", local_rank)
         # weak scaling: `tiles` per rank, stacked along z; strong scaling: `tiles` is the whole box, cut into `world` slabs
         grid = (1, 1, world) if grid is None else tuple(int(v) for v in grid)
-        glob = sysmod.water_box(*[tiles[d] * (1 if strong else grid[d]) for d in range(3)], model=model)
+        whole = [tiles[d] * (1 if strong else grid[d]) for d in range(3)]
+        glob = sysmod.water_box(*whole, model=model) if film is None else sysmod.water_film(*whole, film[0], film[1], model=model)
+        self.glob = glob
         self.natoms_global = glob.natoms
         self.nb = nb = gpu.NbnxnHip(local_rank, local_and_nonlocal=True)
         mcb = nb.min_ci_balanced() if min_ci_balanced is None else min_ci_balanced
@@ -547,7 +648,11 @@ class SlabRun:
         def say(what):
             if verbose:
                 print(f"[dd rank {rank}] {_time.perf_counter() - _t0:6.1f} s  {what}", file=sys.stderr, flush=True)
-        self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims, scheme=scheme)
+        if balance > 0 and world > 1:
+            self.dom = dom = balance_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims, scheme=scheme,
+                                            iterations=balance)[0]
+        else:
+            self.dom = dom = build_domain(glob, ip, rank, world, self.dev, mcb, grid=grid, self_dims=self_dims, scheme=scheme)
         say(f"domain built: {dom.nhome} home + {dom.nhalo} halo atoms, lists {dom.pl_local.nsci} / {dom.pl_nonlocal.nsci} entries")
         nb.init_const(ip, dom.ntype, dom.nbfp)
         if device_search:
@@ -625,7 +730,8 @@ class SlabRun:
         d = self.dom
         return {"dd_grid": list(d.grid), "halo_messages": len(d.msgs), "halo_zones": len(d.zones) - 1,
                 "atoms_rank0": d.nhome, "halo_atoms_rank0": d.nhalo, "nsci_local": d.pl_local.nsci,
-                "nsci_nonlocal": d.pl_nonlocal.nsci, "cluster_pairs_rank0": d.pl_local.nci_tot + d.pl_nonlocal.nci_tot}
+                "nsci_nonlocal": d.pl_nonlocal.nsci, "cluster_pairs_rank0": d.pl_local.nci_tot + d.pl_nonlocal.nci_tot,
+                **({"load_imbalance_per_balancing_step": [round(v, 3) for v in d.balance_history]} if d.balance_history else {})}
 
     def step(self, ev=None):
         nb, fl = self.nb, self.flags

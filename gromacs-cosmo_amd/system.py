@@ -265,6 +265,23 @@ def water_box(nx, ny, nz, model="spc"):
                   excl_index=excl_index, excl_a=excl_a, name=f"{model}216x{nx}x{ny}x{nz}")
 
 
+def water_film(nx, ny, nz, liquid_fraction=0.4, vapour_keep=8, model="spc"):
+    """A liquid film under thin vapour: water_box with, above z = liquid_fraction * box_z, only every
+    `vapour_keep`-th molecule kept.  A density step along z: what an equal-thickness cut balances badly
+    (the workload of the load-balancing tests and of bench.py --dd-balance)."""
+    w = water_box(nx, ny, nz, model=model)
+    nmol = w.natoms // 3
+    z_o = w.x[0::3, 2]
+    keep_mol = (z_o < liquid_fraction * float(w.box[2])) | (np.arange(nmol) % int(vapour_keep) == 0)
+    keep = np.repeat(keep_mol, 3)
+    n = int(keep.sum())
+    excl_index = np.arange(0, 3 * n + 1, 3, dtype=np.int32)
+    base = (np.arange(n, dtype=np.int32) // 3) * 3
+    excl_a = (base[:, None] + np.arange(3, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+    return System(x=np.ascontiguousarray(w.x[keep]), box=w.box, type=np.ascontiguousarray(w.type[keep]), q=np.ascontiguousarray(w.q[keep]),
+                  ntype=w.ntype, c6=w.c6, c12=w.c12, excl_index=excl_index, excl_a=excl_a, name=f"{w.name} film {liquid_fraction:g}/{vapour_keep}")
+
+
 def put_atoms_in_box(x, box):
     """put_atoms_in_box (gmxlib/pbc.c:1562-1625) in float32: every atom shifted by whole box vectors, from z down
     to x, into the brick [0, box[d][d]).  box: [3] or the [3, 3] matrix (rows are box vectors)."""

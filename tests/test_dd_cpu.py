@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims=(2,), scheme="half"):
+def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims=(2,), scheme="half", balance=0):
     import gromacs_cosmo_amd as g
     from gromacs_cosmo_amd import abi, dd
     import oracle as O
@@ -39,10 +39,17 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
         if model == "chains_xy":
             # a cell skewed in the xy plane (box[YY][XX] != 0), box[ZZ] along z: decomposable along z
             glob = g.system.lj_chain_mixture(2744, ntype=5, seed=7, skew=(6, 0, 0))
+        elif model == "film":
+            gr = grid or (1, 1, world)
+            glob = g.system.water_film(2 * gr[0], 2 * gr[1], 3 * gr[2], liquid_fraction=0.4, vapour_keep=6, model="spce")
         else:
             gr = grid or (1, 1, world)
             glob = g.system.water_box(2 * gr[0], 2 * gr[1], 2 * gr[2], model=model)
-        dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims, scheme=scheme)
+        if balance:
+            dom, history = dd.balance_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims,
+                                             scheme=scheme, iterations=balance)
+        else:
+            dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims, scheme=scheme)
         xq_t = torch.from_numpy(dom.xq)                 # aliases dom.xq
         f_t = torch.zeros((dom.npad, 3), dtype=torch.float64)
         halo = dd.HaloExchange(dom, xq_t, f_t)
@@ -87,7 +94,9 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
                          nhome=dom.nhome, nhalo=dom.nhalo, natoms=glob.natoms,
                          nsci=(dom.pl_local.nsci, dom.pl_nonlocal.nsci), nmsg=len(dom.msgs), nzones=len(dom.zones),
                          peers=sorted({m.recv_from for m in dom.msgs}),
-                         nonhome_i=int((dom.pl_nonlocal.sci["sci"] * 64 >= dom.npad_local).sum()))
+                         nonhome_i=int((dom.pl_nonlocal.sci["sci"] * 64 >= dom.npad_local).sum()),
+                         history=dom.balance_history, thickness=(dom.hi - dom.lo).tolist(),
+                         load=dom.pl_local.nci_tot + dom.pl_nonlocal.nci_tot)
     finally:
         dist.destroy_process_group()
 
@@ -153,6 +162,56 @@ def test_eighth_shell_decomposition_matches_single_domain(world, grid, self_dims
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
         assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r
         assert r["vir_err"] < 1e-5, r
+
+
+# Load balancing by the reference's rule (set_dd_cell_sizes_dlb_root, domdec.c:3429-3498) on the ranks' cluster-pair
+# counts: a liquid film under thin vapour, cut into equal slabs / bricks, is far out of balance; the moved planes
+# bring the heaviest rank down, and the decomposed step still equals the single domain.
+@pytest.mark.parametrize("world,grid,scheme", [(4, (1, 1, 4), "half"), (4, (1, 2, 2), "eighth")])
+def test_load_balanced_cuts(world, grid, scheme):
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, _free_port(), "film", 0, ret, grid, (), scheme, 24), nprocs=world, join=True)
+        res = [ret[r] for r in range(world)]
+    assert sum(r["nhome"] for r in res) == res[0]["natoms"]
+    h = res[0]["history"]
+    assert all(r["history"] == h for r in res)
+    loads = np.array([r["load"] for r in res], dtype=np.float64)
+    assert h[0] > 0.8 and loads.max() / loads.mean() - 1 < 0.1, (h, loads)      # from 80-130 % over the mean to under 10 %
+    assert len({round(r["thickness"][2], 4) for r in res}) > 1      # the planes moved
+    for r in res:
+        assert min(r["thickness"]) > 0.9
+        # relative to the forces of the rank's own atoms, which are small where the rank holds vapour (4e-6 there
+        # with equal slabs, too: the float32 rounding of z + box_z of the imported atoms)
+        assert r["err"] < 1e-5, r
+        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r
+        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-6 * abs(r["e_el_ref"]), r
+        assert r["vir_err"] < 1e-5, r
+
+
+def test_dlb_rule():
+    """dlb_update_cuts against the reference's arithmetic worked by hand (domdec.c:3469-3497): relax 0.5, the whole
+    row scaled when the largest change exceeds 10 %, the minimum cell size enforced"""
+    from gromacs_cosmo_amd import dd
+    cuts = dd.uniform_cuts((1, 1, 4))
+    # loads 4 ranks along z: mean 100; imbalances +1, 0, -0.5, -0.5 -> changes -0.5, 0, .25, .25, largest 0.5 > 0.1 -> sc = 0.1
+    new = dd.dlb_update_cuts(cuts, (1, 1, 4), [200, 100, 50, 50], (0, 0, 0))
+    size = 0.25 * (1 - 0.1 * np.array([1.0, 0.0, -0.5, -0.5]))
+    assert np.allclose(np.diff(new[2]), size / size.sum(), rtol=0, atol=1e-12)
+    assert np.array_equal(new[0], cuts[0]) and np.array_equal(new[1], cuts[1])
+    # small imbalance: the plain underrelaxed step
+    new = dd.dlb_update_cuts(cuts, (1, 1, 4), [104, 100, 98, 98], (0, 0, 0))
+    size = 0.25 * (1 - 0.5 * np.array([0.04, 0.0, -0.02, -0.02]))
+    assert np.allclose(np.diff(new[2]), size / size.sum(), rtol=0, atol=1e-12)
+    # the limit: a cell already at the minimum stays there, the others share the rest
+    new = dd.dlb_update_cuts((cuts[0], cuts[1], np.array([0.0, 0.2, 0.5, 0.75, 1.0])), (1, 1, 4), [200, 100, 50, 50], (0, 0, 0.2))
+    d = np.diff(new[2])
+    assert abs(d[0] - 0.2) < 1e-12 and abs(d.sum() - 1) < 1e-12 and (d[1:] > 0.2).all()
+    # rows of a 2 x 2 grid in y and z: row loads are sums over the other dimension
+    new = dd.dlb_update_cuts(dd.uniform_cuts((1, 2, 2)), (1, 2, 2), [30, 10, 30, 10], (0, 0, 0))     # ranks (y0,z0) (y1,z0) (y0,z1) (y1,z1)
+    assert np.diff(new[1])[0] < 0.5 and np.allclose(np.diff(new[2]), 0.5)
+    with pytest.raises(ValueError):
+        dd.dlb_update_cuts(cuts, (1, 1, 4), [1, 1, 1, 1], (0, 0, 0.3))
 
 
 def test_decomposition_across_a_skewed_box_vector_is_refused():

@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 DEADLINE_S = 100
 
 
-def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_direct=False, grid=None, self_dims=(2,), scheme="half"):
+def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_direct=False, grid=None, self_dims=(2,), scheme="half",
+            balance=0, film=None):
     import datetime
     import faulthandler
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -44,7 +45,7 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
         ip = g.system.reaction_field(0.9, rlist=1.0) if model == "spc" else g.system.ewald(0.9, rlist=1.0)
         tiles = (2, 2, 2)
         run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
-                         rccl_direct=rccl_direct, grid=grid, self_dims=self_dims, scheme=scheme)
+                         rccl_direct=rccl_direct, grid=grid, self_dims=self_dims, scheme=scheme, balance=balance, film=film)
         dom = run.dom
         assert len(dom.msgs) == ({1: 1, 2: 4, 3: 13} if scheme == "half" else {1: 1, 2: 3, 3: 7})[sum(dom.decomp)]
         # wreck the imported coordinates on the device: the step has to bring them back
@@ -53,8 +54,7 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
             run.step()
         f_home = run.forces_home()
         e = run.read_energies().cpu().numpy()
-        gr = grid or (1, 1, world)
-        glob = g.system.water_box(tiles[0] * gr[0], tiles[1] * gr[1], tiles[2] * gr[2], model=model)
+        glob = run.glob
         prep = g.workload.prepare(glob, ip, 0)
         o = O.kernel_gpu_list(prep.xq, prep.type, prep.ntype, prep.nbfp, prep.shift_vec, prep.pl, ip)
         f_ref = np.zeros((glob.natoms, 3), dtype=np.float32)
@@ -92,7 +92,8 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
             err_moved = float(np.sqrt(((f_moved - frm) ** 2).sum() / (frm ** 2).sum()))
         ret[rank] = dict(err=float(np.sqrt(((f_home - fr) ** 2).sum() / (fr ** 2).sum())), err_moved=err_moved,
                          e_lj=float(e[0]), e_el=float(e[1]), e_lj_ref=float(o["Vvdw"]), e_el_ref=float(o["Vc"]),
-                         vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()))
+                         vir_err=float(np.abs(vir_dd - vir_ref).max() / np.abs(vir_ref).max()),
+                         history=dom.balance_history, load=dom.pl_local.nci_tot + dom.pl_nonlocal.nci_tot)
     finally:
         dist.destroy_process_group()
         faulthandler.cancel_dump_traceback_later()
@@ -151,6 +152,24 @@ def test_slabrun_one_rank_over_rccl(model, rccl_direct, reserve_cus, monkeypatch
     assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
     assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
     assert r["vir_err"] < 1e-5, r
+
+
+def test_load_balanced_slabs_two_ranks_one_gpu():
+    """A liquid film under thin vapour on two z slabs: the cut plane moved by the reference's balancing rule on the
+    ranks' cluster-pair counts (dd.balance_domain; the rule itself and four ranks: tests/test_dd_cpu.py), then the
+    decomposed step on the device with the grids and lists of the unequal slabs made by the device search."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_worker, args=(2, _free_port(), "spce", True, ret, "gloo", False, (1, 1, 2), (), "half", 24, (0.4, 6)), nprocs=2, join=False))
+        res = [ret[r] for r in range(2)]
+    h = res[0]["history"]
+    loads = [r["load"] for r in res]
+    assert h[0] > 0.5 and max(loads) / (sum(loads) / 2) - 1 < 0.1, (h, loads)
+    for r in res:
+        assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
+        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
+        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
+        assert r["vir_err"] < 1e-5, r
 
 
 def test_brickrun_two_ranks_cut_along_x_one_gpu():
