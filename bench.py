@@ -300,8 +300,9 @@ def main():
     ap.add_argument("--precondition", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up steps, so that the timed region runs at the clock the GPU sustains")
     ap.add_argument("--dd-grid", default="", help="ranks along x,y,z (default 1,1,N: z slabs); e.g. 2,2,2 for --gpus 8")
-    ap.add_argument("--dd-scheme", default="auto", choices=["auto", "half", "eighth"],
-                    help="half shell with home i-clusters only, or the reference's eighth shell with pairs between imported zones; "
+    ap.add_argument("--dd-scheme", default="auto", choices=["auto", "half", "eighth", "staged"],
+                    help="half shell with home i-clusters only, or the reference's eighth shell with pairs between imported zones "
+                         "(staged: its zones brought by the reference's pulses, one per dimension, instead of direct messages); "
                          "auto: the eighth shell when three dimensions are cut (7 messages instead of 13), else the half shell")
     ap.add_argument("--dd-self-dims", default="2", help="with --dd-self: the dimensions the one rank is its own neighbour in (0,1,2 = the 13-message step)")
     ap.add_argument("--dd-film", default="", help="liquid_fraction,vapour_keep: a liquid film under thin vapour instead of the full box "

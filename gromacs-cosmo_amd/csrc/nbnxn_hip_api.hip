@@ -214,6 +214,10 @@ struct nbnxn_hip {
     // the halo messages of a step (nbnxn_hip_dd_set_messages): rows of message k start at dd_send_off[k] / dd_recv_off[k]
     // (multiples of 64) in the slot lists and buffers; coordinates go to send_to, forces come back from it
     int              dd_nmsg = 0;
+    // phases of an exchange (nbnxn_hip_dd_set_phases): messages [dd_phase_end[p - 1], dd_phase_end[p]) travel together, the
+    // phases one after the other (the reference's pulses per dimension, whose later ones forward what earlier ones brought)
+    int              dd_nphase = 0;
+    int              dd_phase_end[NBX_DD_MAX_MESSAGES];
     nbx_dd_message_t dd_msg[NBX_DD_MAX_MESSAGES];
     int              dd_send_off[NBX_DD_MAX_MESSAGES], dd_recv_off[NBX_DD_MAX_MESSAGES];
     int              dd_send_rows = 0, dd_recv_rows = 0;   // padded totals
@@ -1848,6 +1852,7 @@ int nbnxn_hip_dd_finish(nbnxn_hip_ptr_t nb)
     dev_free(nb->dd_send_slots); dev_free(nb->dd_recv_slots); dev_free(nb->dd_send_wave_msg); dev_free(nb->dd_msg_shift);
     dev_free(nb->dd_x_out); dev_free(nb->dd_x_in); dev_free(nb->dd_f_out); dev_free(nb->dd_f_in);
     nb->dd_nmsg = 0;
+    nb->dd_nphase = 0;
     return 0;
 }
 
@@ -1907,7 +1912,39 @@ int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message
     HIP_TRY(hipStreamSynchronize(st));
     nb->dd_send_rows = (int)h_send.size(); nb->dd_recv_rows = (int)h_recv.size();
     nb->dd_nmsg = nmsg;
+    nb->dd_nphase = 1; nb->dd_phase_end[0] = nmsg;      // all at once until nbnxn_hip_dd_set_phases says otherwise
     return 0;
+}
+
+int nbnxn_hip_dd_set_phases(nbnxn_hip_ptr_t nb, int nphase, const int *phase_end)
+{
+    if (check_dd(nb)) { return 1; }
+    if (nb->dd_nmsg == 0) { return nbx_fail("dd_set_phases before dd_set_messages"); }
+    if (nphase < 1 || nphase > nb->dd_nmsg || !phase_end) { return nbx_fail("dd_set_phases: %d phases for %d messages", nphase, nb->dd_nmsg); }
+    for (int p = 0; p < nphase; p++)
+    {
+        if (phase_end[p] <= (p ? phase_end[p - 1] : 0)) { return nbx_fail("dd_set_phases: phase %d ends at message %d, not behind the phase before it", p, phase_end[p]); }
+    }
+    if (phase_end[nphase - 1] != nb->dd_nmsg) { return nbx_fail("dd_set_phases: the last phase ends at message %d of %d", phase_end[nphase - 1], nb->dd_nmsg); }
+    HIP_TRY(hipSetDevice(nb->device));
+    HIP_TRY(hipStreamSynchronize(dd_stream(nb, NBX_NONLOCAL)));     // no step in flight reads the phases, but keep the order of set-up calls simple
+    nb->dd_nphase = nphase;
+    for (int p = 0; p < nphase; p++) { nb->dd_phase_end[p] = phase_end[p]; }
+    return 0;
+}
+
+namespace {
+// rows [r0, r1) of the padded send / receive layouts that the messages [k0, k1) occupy
+struct PhaseRows { int k0, k1, s0, s1, r0, r1; };
+PhaseRows phase_rows(const nbnxn_hip *nb, int p)
+{
+    PhaseRows R;
+    R.k0 = p ? nb->dd_phase_end[p - 1] : 0;
+    R.k1 = nb->dd_phase_end[p];
+    R.s0 = nb->dd_send_off[R.k0]; R.s1 = R.k1 < nb->dd_nmsg ? nb->dd_send_off[R.k1] : nb->dd_send_rows;
+    R.r0 = nb->dd_recv_off[R.k0]; R.r1 = R.k1 < nb->dd_nmsg ? nb->dd_recv_off[R.k1] : nb->dd_recv_rows;
+    return R;
+}
 }
 
 int nbnxn_hip_dd_set_pulse(nbnxn_hip_ptr_t nb, int send_to, int recv_from, const int *send_slots, int n_send,
@@ -1928,17 +1965,24 @@ int nbnxn_hip_dd_move_x(nbnxn_hip_ptr_t nb)
     hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
     // the home coordinates the pack kernel reads may still be on their way on the local stream (x gather, H2D)
     if (wait_x_written(nb, st)) { return 1; }
-    HIP_TRY(nbx_launch_halo_pack_x_msgs(nb->dd_send_slots.p, nb->dd_send_rows, nb->xq.p, nb->dd_send_wave_msg.p,
-                                        reinterpret_cast<const float4 *>(nb->dd_msg_shift.p), reinterpret_cast<float4 *>(nb->dd_x_out.p), st));
-    RCCL_TRY(g_rccl.GroupStart());
-    for (int k = 0; k < nb->dd_nmsg; k++)
+    // phase by phase (one phase unless nbnxn_hip_dd_set_phases split the messages): a later phase may send what an
+    // earlier one brought (dd_move_x, domdec.c:667-758: the pulses of the later dimensions forward the earlier zones)
+    for (int p = 0; p < nb->dd_nphase; p++)
     {
-        const nbx_dd_message_t &m = nb->dd_msg[k];
-        if (m.n_send > 0) { RCCL_TRY(g_rccl.Send(nb->dd_x_out.p + (size_t)nb->dd_send_off[k] * 4, (size_t)m.n_send * 4, ncclFloat, m.send_to, nb->dd_comm, st)); }
-        if (m.n_recv > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_x_in.p + (size_t)nb->dd_recv_off[k] * 4, (size_t)m.n_recv * 4, ncclFloat, m.recv_from, nb->dd_comm, st)); }
+        const PhaseRows R = phase_rows(nb, p);
+        HIP_TRY(nbx_launch_halo_pack_x_msgs(nb->dd_send_slots.p + R.s0, R.s1 - R.s0, nb->xq.p, nb->dd_send_wave_msg.p + R.s0 / 64,
+                                            reinterpret_cast<const float4 *>(nb->dd_msg_shift.p),
+                                            reinterpret_cast<float4 *>(nb->dd_x_out.p) + R.s0, st));
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int k = R.k0; k < R.k1; k++)
+        {
+            const nbx_dd_message_t &m = nb->dd_msg[k];
+            if (m.n_send > 0) { RCCL_TRY(g_rccl.Send(nb->dd_x_out.p + (size_t)nb->dd_send_off[k] * 4, (size_t)m.n_send * 4, ncclFloat, m.send_to, nb->dd_comm, st)); }
+            if (m.n_recv > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_x_in.p + (size_t)nb->dd_recv_off[k] * 4, (size_t)m.n_recv * 4, ncclFloat, m.recv_from, nb->dd_comm, st)); }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(nbx_launch_halo_unpack_x(nb->dd_recv_slots.p + R.r0, R.r1 - R.r0, reinterpret_cast<const float4 *>(nb->dd_x_in.p) + R.r0, nb->xq.p, st));
     }
-    RCCL_TRY(g_rccl.GroupEnd());
-    HIP_TRY(nbx_launch_halo_unpack_x(nb->dd_recv_slots.p, nb->dd_recv_rows, reinterpret_cast<const float4 *>(nb->dd_x_in.p), nb->xq.p, st));
     return 0;
 }
 
@@ -1948,19 +1992,25 @@ int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb)
     if (nb->dd_nmsg == 0) { return nbx_fail("dd_move_f before dd_set_pulse / dd_set_messages"); }
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
-    HIP_TRY(nbx_launch_halo_pack_f(nb->dd_recv_slots.p, nb->dd_recv_rows, nb->f.p, nb->dd_f_out.p, st));
-    // the reverse path: forces on imported atoms go back to where the coordinates came from
-    RCCL_TRY(g_rccl.GroupStart());
-    for (int k = 0; k < nb->dd_nmsg; k++)
+    // the reverse path: forces on imported atoms go back to where the coordinates came from; the phases in reverse
+    // order, so that what a later phase returns to a forwarded atom travels on with the earlier one (dd_move_f,
+    // domdec.c:784-870)
+    for (int p = nb->dd_nphase - 1; p >= 0; p--)
     {
-        const nbx_dd_message_t &m = nb->dd_msg[k];
-        if (m.n_recv > 0) { RCCL_TRY(g_rccl.Send(nb->dd_f_out.p + (size_t)nb->dd_recv_off[k] * 3, (size_t)m.n_recv * 3, ncclFloat, m.recv_from, nb->dd_comm, st)); }
-        if (m.n_send > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_f_in.p + (size_t)nb->dd_send_off[k] * 3, (size_t)m.n_send * 3, ncclFloat, m.send_to, nb->dd_comm, st)); }
+        const PhaseRows R = phase_rows(nb, p);
+        HIP_TRY(nbx_launch_halo_pack_f(nb->dd_recv_slots.p + R.r0, R.r1 - R.r0, nb->f.p, nb->dd_f_out.p + (size_t)R.r0 * 3, st));
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int k = R.k0; k < R.k1; k++)
+        {
+            const nbx_dd_message_t &m = nb->dd_msg[k];
+            if (m.n_recv > 0) { RCCL_TRY(g_rccl.Send(nb->dd_f_out.p + (size_t)nb->dd_recv_off[k] * 3, (size_t)m.n_recv * 3, ncclFloat, m.recv_from, nb->dd_comm, st)); }
+            if (m.n_send > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_f_in.p + (size_t)nb->dd_send_off[k] * 3, (size_t)m.n_send * 3, ncclFloat, m.send_to, nb->dd_comm, st)); }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        // into accumulation slot 0 of the output in use for the messages that crossed a periodic boundary
+        HIP_TRY(nbx_launch_halo_unpack_f_msgs(nb->dd_send_slots.p + R.s0, R.s1 - R.s0, nb->dd_f_in.p + (size_t)R.s0 * 3, nb->f.p,
+                                              nb->dd_send_wave_msg.p + R.s0 / 64, reinterpret_cast<const float4 *>(nb->dd_msg_shift.p), nb->out, st));
     }
-    RCCL_TRY(g_rccl.GroupEnd());
-    // into accumulation slot 0 of the output in use for the messages that crossed a periodic boundary
-    HIP_TRY(nbx_launch_halo_unpack_f_msgs(nb->dd_send_slots.p, nb->dd_send_rows, nb->dd_f_in.p, nb->f.p, nb->dd_send_wave_msg.p,
-                                          reinterpret_cast<const float4 *>(nb->dd_msg_shift.p), nb->out, st));
     return 0;
 }
 

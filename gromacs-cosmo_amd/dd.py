@@ -19,6 +19,8 @@ halo f).  The path's multi-GPU form here has the same data flow with a simpler z
     volume in both schemes (13x13x14 tiles on 2x2x2 ranks: 28 % of the home atoms here, 26 % there), and one grouped
     RCCL call moves all messages at once.  Measured on one rank that is its own neighbour: a tie with two cut dimensions,
     the eighth shell 21 % faster with three (7 messages and zones instead of 13): see scheme="eighth" below.  Bricks must be thicker than rlist so that only neighbours interact;
+  * scheme="staged": the same zones and lists brought by the reference's pulses, one per cut dimension, later ones forwarding what
+    earlier ones brought (_staged_pulses, StagedHalo, nbnxn_hip_dd_set_phases); measured 14-16 % slower than the direct messages;
   * scheme="eighth" is the reference's own zone scheme with the same direct messages: the 1 / 3 / 7 zones of dd_zo, and the
     zone pairs of dd_zp1 / dd_zp2 / dd_zp3 in the lists, so the non-local list also holds pairs BETWEEN imported zones and its
     i-clusters are not all home clusters (what stock mdrun's search hands the kernel under domain decomposition).  The host
@@ -288,6 +290,61 @@ def balance_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, 
     return dom, history
 
 
+def _staged_pulses(decomp, grid, me, rank, box, lo, rl, home_ids, x_home, device):
+    """The reference's communication set-up for one pulse per cut dimension (setup_dd_communication, domdec.c:8100-8500,
+    with cells thicker than the cut-off; dd_move_x, :667-758): along x, then y, then z, a rank sends the neighbour below
+    everything it HOLDS within rlist of its lower face -- home atoms and what the earlier pulses brought -- so the
+    pulse along y forwards zone (1,0,0) as the receiver's zone (1,1,0), and the pulse along z forwards three zones.
+    The atoms of a pulse travel grouped by the zone they become, in dd_zo order, so the imported atoms end up in zone
+    order 1 .. 2^ndim - 1 and the grids and lists are those of the eighth shell with direct messages."""
+    dims = [d for d in range(3) if decomp[d]]
+    zo = [tuple(v[:len(dims)]) for v in DD_ZO[:2 ** len(dims)]]
+    zone_index = {v: k for k, v in enumerate(zo)}
+    ids_held, x_held = home_ids.astype(np.int64), x_home.astype(np.float32)
+    zone_held = np.zeros(len(home_ids), dtype=np.int64)
+    zone_n = {0: len(home_ids)}
+    msgs, sels = [], []
+    for k, d in enumerate(dims):
+        near = np.nonzero((x_held[:, d] - np.float32(lo[d])) < rl)[0]
+        becomes = np.array([zone_index[tuple(1 if j == k else zo[z][j] for j in range(len(dims)))] for z in range(len(zo))])[zone_held[near]]
+        sel = near[np.argsort(becomes, kind="stable")]
+        t = [0, 0, 0]
+        t[d] = 1 if me[d] == 0 else 0                          # the receiver sits at the top of the box: + box
+        shift = np.array([t[j] * float(box[j]) for j in range(3)], dtype=np.float32)
+        o = tuple(1 if j == d else 0 for j in range(3))
+        send_to = rank_of([(me[j] - o[j]) % grid[j] for j in range(3)], grid)
+        recv_from = rank_of([(me[j] + o[j]) % grid[j] for j in range(3)], grid)
+        cnt_send = torch.from_numpy(np.bincount(becomes, minlength=8).astype(np.int64)).to(device)
+        cnt_recv = torch.zeros(8, dtype=torch.int64, device=device)
+        _exchange(cnt_send, send_to, cnt_recv, recv_from)
+        cnt = cnt_recv.cpu().numpy()
+        nr = int(cnt.sum())
+        ids_recv = torch.zeros(nr, dtype=torch.int64, device=device)
+        x_recv = torch.zeros((nr, 3), dtype=torch.float32, device=device)
+        _exchange(torch.from_numpy(ids_held[sel]).to(device), send_to, ids_recv, recv_from)
+        _exchange(torch.from_numpy(x_held[sel] + shift).to(device), send_to, x_recv, recv_from)
+        msgs.append(Message(offset=o, send_to=send_to, recv_from=recv_from, n_send=len(sel), n_recv=nr, shift=shift,
+                            shift_index=shift_index(*t) if any(t) else -1))
+        sels.append(sel)
+        ids_held = np.concatenate([ids_held, ids_recv.cpu().numpy()])
+        x_held = np.concatenate([x_held, x_recv.cpu().numpy()])
+        zone_held = np.concatenate([zone_held, np.repeat(np.arange(8), cnt)])
+        for z in range(8):
+            if cnt[z]:
+                zone_n[z] = int(cnt[z])
+    nhome = len(home_ids)
+    zone_parts, a = [], nhome
+    for z in range(1, len(zo)):
+        off = [0, 0, 0]
+        for j, d in enumerate(dims):
+            off[d] = zo[z][j]
+        n = zone_n.get(z, 0)
+        zone_parts.append((tuple(off), n, x_held[a:a + n]))
+        a += n
+    assert a == len(ids_held) and (np.diff(zone_held) >= 0).all()
+    return msgs, sels, [ids_held[nhome:]], [x_held[nhome:]], zone_parts
+
+
 def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, self_dims=(2,), scheme="half", cuts=None):
     """Cuts rank `rank`'s brick out of the global system `glob` (every rank holds the synthetic
     global topology; coordinates of imported atoms still arrive by message, as they would in a
@@ -342,9 +399,12 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
     rl = np.float32(ip.rlist)
 
     msgs, sels, halo_id_parts, halo_x_parts = [], [], [], []
-    if scheme not in ("half", "eighth"):
+    if scheme not in ("half", "eighth", "staged"):
         raise ValueError(f"unknown decomposition scheme {scheme!r}")
-    for o in forward_offsets(decomp, scheme):
+    zone_parts = None
+    if scheme == "staged":
+        msgs, sels, halo_id_parts, halo_x_parts, zone_parts = _staged_pulses(decomp, grid, me, rank, box, lo, rl, home_ids, x_home, device)
+    for o in (forward_offsets(decomp, scheme) if scheme != "staged" else ()):
         # what the rank at me - o imports from me: my atoms within rlist of the face / edge / corner we share
         sel = np.ones(nhome, dtype=bool)
         t = [0, 0, 0]
@@ -387,16 +447,18 @@ def build_domain(glob, ip, rank, world, device, min_ci_balanced=0, grid=None, se
     zones = [(tuple(c0), tuple(c1), 0, nhome)]
     host.put_on_grid(0, zones[0][0], zones[0][1], 0, x_home)
     a0 = nhome
-    for m, xh in zip(msgs, halo_x_parts):
-        if m.n_recv == 0:
-            if scheme == "eighth":
-                raise ValueError(f"zone {m.offset} of the eighth shell is empty: the zone pairs need every zone on the grid")
+    if zone_parts is None:
+        zone_parts = [(m.offset, m.n_recv, xh) for m, xh in zip(msgs, halo_x_parts)]      # one zone per message
+    for off, nz, xh in zone_parts:
+        if nz == 0:
+            if scheme != "half":
+                raise ValueError(f"zone {off} of the eighth shell is empty: the zone pairs need every zone on the grid")
             continue
-        z0 = [c1[d] if m.offset[d] == 1 else (c0[d] - float(rl) if m.offset[d] == -1 else c0[d]) for d in range(3)]
-        z1 = [c1[d] + float(rl) if m.offset[d] == 1 else (c0[d] if m.offset[d] == -1 else c1[d]) for d in range(3)]
-        zones.append((tuple(z0), tuple(z1), a0, m.n_recv))
+        z0 = [c1[d] if off[d] == 1 else (c0[d] - float(rl) if off[d] == -1 else c0[d]) for d in range(3)]
+        z1 = [c1[d] + float(rl) if off[d] == 1 else (c0[d] if off[d] == -1 else c1[d]) for d in range(3)]
+        zones.append((tuple(z0), tuple(z1), a0, nz))
         host.put_on_grid(len(zones) - 1, zones[-1][0], zones[-1][1], a0, xh)
-        a0 += m.n_recv
+        a0 += nz
     if len(zones) > abi.MAX_ZONES:
         raise ValueError(f"{len(zones)} grid zones, the search takes {abi.MAX_ZONES}")
     ids_all = np.concatenate([home_ids, halo_ids])
@@ -517,6 +579,44 @@ class HaloExchange:
             out_t[2:2 + 3 * abi.SHIFTS] += self.fshift_wrap.reshape(-1).to(out_t.dtype)
 
 
+class _PulseView:
+    """What the exchange classes read of a Domain, for ONE of its messages"""
+
+    def __init__(self, dom, k):
+        s0, r0 = sum(m.n_send for m in dom.msgs[:k]), sum(m.n_recv for m in dom.msgs[:k])
+        self.msgs, self.world, self.rank = [dom.msgs[k]], dom.world, dom.rank
+        self.send_slots = dom.send_slots[s0:s0 + dom.msgs[k].n_send]
+        self.halo_slots = dom.halo_slots[r0:r0 + dom.msgs[k].n_recv]
+
+
+class StagedHalo:
+    """The reference's staged pulses on top of either exchange class (dd_move_x, domdec.c:667-758; dd_move_f, :784-870):
+    one exchange per pulse, coordinates in pulse order -- a later pulse sends slots an earlier one filled --, forces in
+    reverse order, so that what comes back for a forwarded atom is in its slot before that slot's own pulse returns it.
+    make(view) builds the one-message exchange of a pulse (HaloExchange or DeviceHalo)."""
+
+    def __init__(self, make, dom):
+        self.parts = [make(_PulseView(dom, k)) for k in range(len(dom.msgs))]
+        self.halo_slots = torch.cat([p.halo_slots.to(torch.int64) for p in self.parts])
+        self.wrap_seg = [s for p in self.parts for s in getattr(p, "wrap_seg", [])]
+
+    def send_x(self):
+        for p in self.parts:
+            p.send_x()
+
+    def return_f(self):
+        for p in reversed(self.parts):
+            p.return_f()
+
+    @property
+    def fshift_wrap(self):
+        return sum(p.fshift_wrap for p in self.parts)
+
+    def add_wrap_fshift(self, out_t):
+        for p in self.parts:
+            p.add_wrap_fshift(out_t)
+
+
 class DeviceHalo:
     """The same messages with the buffers packed and unpacked by the HIP module's halo kernels
     (nbnxn_hip_halo_*) on its non-local stream, and the shift-force term of a periodic crossing added by the
@@ -574,6 +674,8 @@ class RcclHalo:
         self.halo_slots = torch.from_numpy(dom.halo_slots.astype(np.int64)).to(dev)
         nb.dd_set_messages([(m.send_to, m.recv_from, m.n_send, m.n_recv, m.shift_index, m.shift) for m in dom.msgs],
                            dom.send_slots, dom.halo_slots)
+        if dom.scheme == "staged":
+            nb.dd_set_phases(list(range(1, len(dom.msgs) + 1)))      # every pulse a phase of its own (nbnxn_hip_dd_set_phases)
 
     def send_x(self):
         self.nb.dd_move_x()
@@ -706,7 +808,8 @@ class SlabRun:
         if rccl_direct:
             self.halo = RcclHalo(nb, dom, self.dev)
         else:
-            self.halo = DeviceHalo(nb, dom, self.dev) if device_halo else HaloExchange(dom, self.xq_t, self.f_t)
+            make = (lambda d: DeviceHalo(nb, d, self.dev)) if device_halo else (lambda d: HaloExchange(d, self.xq_t, self.f_t))
+            self.halo = StagedHalo(make, dom) if dom.scheme == "staged" else make(dom)
         self.s_loc = torch.cuda.ExternalStream(nb.stream(abi.LOCAL), device=self.dev)
         self.s_nl = torch.cuda.ExternalStream(nb.stream(abi.NONLOCAL), device=self.dev)
         self.s_default = torch.cuda.default_stream(self.dev)

@@ -123,6 +123,7 @@ def load():
     lib.nbnxn_hip_dd_init.argtypes = [vp, C.c_char_p, ci, ci]
     lib.nbnxn_hip_dd_set_pulse.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci]
     lib.nbnxn_hip_dd_set_messages.argtypes = [vp, ci, vp, vp, vp]
+    lib.nbnxn_hip_dd_set_phases.argtypes = [vp, ci, vp]
     lib.nbnxn_hip_dd_move_x.argtypes = [vp]
     lib.nbnxn_hip_dd_step.argtypes = [vp, ci, ci, ci, vp, vp]
     lib.nbnxn_hip_dd_move_f.argtypes = [vp]
@@ -441,6 +442,10 @@ class NbnxnHip:
         rs = np.ascontiguousarray(recv_slots, dtype=np.int32)
         assert len(ss) == sum(m[2] for m in msgs) and len(rs) == sum(m[3] for m in msgs)
         self._chk(self.lib.nbnxn_hip_dd_set_messages(self.h, len(msgs), ms, abi.ptr(ss), abi.ptr(rs)))
+
+    def dd_set_phases(self, phase_end):
+        pe = np.ascontiguousarray(phase_end, dtype=np.int32)
+        self._chk(self.lib.nbnxn_hip_dd_set_phases(self.h, len(pe), abi.ptr(pe)))
 
     def dd_step(self, flags, sum_last_outputs, exchange_beside_local, ev_before_local=None, ev_after_local=None):
         self._chk(self.lib.nbnxn_hip_dd_step(self.h, flags, int(sum_last_outputs), int(exchange_beside_local), ev_before_local, ev_after_local))

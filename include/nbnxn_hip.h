@@ -639,6 +639,14 @@ typedef struct {
     float shift[3];
 } nbx_dd_message_t;
 int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message_t *msg, const int *send_slots, const int *recv_slots);
+/* The reference's staged pulses (dd_move_x, domdec.c:667-758; dd_move_f, :784-870): the messages of
+ * nbnxn_hip_dd_set_messages split into nphase phases, phase p = messages [phase_end[p - 1], phase_end[p]).  The
+ * coordinate exchange runs the phases in order (pack, grouped send / receive, unpack, each behind the one before on
+ * the non-local stream), so a later phase may send slots that an earlier phase filled -- the pulse of a later
+ * dimension forwards the zones the earlier dimensions brought; the force exchange runs them in reverse order, so
+ * what comes back for a forwarded atom is added to its slot before that slot's own pulse returns it.  Send slots of
+ * one phase must be distinct.  Default after nbnxn_hip_dd_set_messages: one phase. */
+int nbnxn_hip_dd_set_phases(nbnxn_hip_ptr_t nb, int nphase, const int *phase_end);
 /* dd_move_x / dd_move_f for that pulse (or those messages), asynchronous on the non-local stream; every rank calls them.
  * Ordering: the pack kernel of dd_move_x (and nbnxn_hip_halo_pack_x) waits for the last write of home coordinates
  * that this library issued on the LOCAL stream (the H2D of nbnxn_hip_launch_kernel / nbnxn_hip_upload_xq_flat, the

@@ -52,7 +52,7 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
             dom = dd.build_domain(glob, ip, rank, world, torch.device("cpu"), min_ci_balanced, grid=grid, self_dims=self_dims, scheme=scheme)
         xq_t = torch.from_numpy(dom.xq)                 # aliases dom.xq
         f_t = torch.zeros((dom.npad, 3), dtype=torch.float64)
-        halo = dd.HaloExchange(dom, xq_t, f_t)
+        halo = dd.StagedHalo(lambda d: dd.HaloExchange(d, xq_t, f_t), dom) if scheme == "staged" else dd.HaloExchange(dom, xq_t, f_t)
         # the imported coordinates must really arrive by message: wreck them first
         want = dom.xq[dom.halo_slots].copy()
         dom.xq[dom.halo_slots, :3] = 1e6
@@ -63,7 +63,7 @@ def _worker(rank, world, port, model, min_ci_balanced, ret, grid=None, self_dims
         o_n = O.kernel_gpu_list(dom.xq, dom.type, dom.ntype, dom.nbfp, dom.shift_vec, dom.pl_nonlocal, ip)
         f_t += torch.from_numpy(np.asarray(o_l["f"], dtype=np.float64) + np.asarray(o_n["f"], dtype=np.float64))
         # non-local entries only touch home i-atoms and halo j-atoms
-        assert dom.pl_nonlocal.nsci > 0 and (scheme == "eighth" or dom.pl_nonlocal.sci["sci"].max() * 64 < dom.npad_local)
+        assert dom.pl_nonlocal.nsci > 0 and (scheme != "half" or dom.pl_nonlocal.sci["sci"].max() * 64 < dom.npad_local)
         halo.return_f()
         out = torch.zeros((abi.OUT_SLOTS, abi.OUT_STRIDE), dtype=torch.float64)
         out[0, 0] = o_l["Vvdw"] + o_n["Vvdw"]
@@ -148,15 +148,18 @@ def test_brick_decomposition_matches_single_domain(world, grid, self_dims, model
 @pytest.mark.parametrize("world,grid,self_dims,model,mcb", [
     (4, (2, 2, 1), (), "spce", 0), (4, (1, 2, 2), (), "spc", 150), (8, (2, 2, 2), (), "spce", 0), (6, (3, 2, 1), (), "spc", 0),
     (1, (1, 1, 1), (0, 1, 2), "spce", 0), (2, (1, 1, 2), (), "spc", 0)])
-def test_eighth_shell_decomposition_matches_single_domain(world, grid, self_dims, model, mcb):
+@pytest.mark.parametrize("scheme", ["eighth", "staged"])
+def test_eighth_shell_decomposition_matches_single_domain(world, grid, self_dims, model, mcb, scheme):
+    """scheme "staged": the same zones brought by the reference's pulses, one per cut dimension, the later ones forwarding
+    what the earlier ones brought (dd_move_x / dd_move_f, domdec.c:667-870); same lists, same result."""
     with mp.Manager() as m:
         ret = m.dict()
-        mp.spawn(_worker, args=(world, _free_port(), model, mcb, ret, grid, self_dims, "eighth"), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), model, mcb, ret, grid, self_dims, scheme), nprocs=world, join=True)
         res = [ret[r] for r in range(world)]
     assert sum(r["nhome"] for r in res) == res[0]["natoms"]
     ncut = sum(1 for d in range(3) if grid[d] > 1 or (world == 1 and d in self_dims))
     for r in res:
-        assert r["nmsg"] == {1: 1, 2: 3, 3: 7}[ncut] and r["nzones"] == r["nmsg"] + 1
+        assert r["nmsg"] == ({1: 1, 2: 3, 3: 7}[ncut] if scheme == "eighth" else ncut) and r["nzones"] == 2 ** ncut
         assert (r["nonhome_i"] > 0) == (ncut > 1)        # zone x zone pairs exist from two cut dimensions on
         assert r["err"] < 2e-6, r
         assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-6 * abs(r["e_lj_ref"]), r

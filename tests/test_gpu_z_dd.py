@@ -47,7 +47,7 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
         run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
                          rccl_direct=rccl_direct, grid=grid, self_dims=self_dims, scheme=scheme, balance=balance, film=film)
         dom = run.dom
-        assert len(dom.msgs) == ({1: 1, 2: 4, 3: 13} if scheme == "half" else {1: 1, 2: 3, 3: 7})[sum(dom.decomp)]
+        assert len(dom.msgs) == {"half": {1: 1, 2: 4, 3: 13}, "eighth": {1: 1, 2: 3, 3: 7}, "staged": {1: 1, 2: 2, 3: 3}}[scheme][sum(dom.decomp)]
         # wreck the imported coordinates on the device: the step has to bring them back
         run.xq_t[run.halo.halo_slots, :3] = 1e6
         for _ in range(3):
@@ -210,10 +210,28 @@ def test_eighth_shell_one_rank_over_rccl(self_dims):
     """The reference's eighth shell (dd_zo / dd_zp3, domdec.c:432-449) on the GPU: 7 (3) imported zones on one rank that is
     its own neighbour in three (two) dimensions, messages over RCCL issued by the module, and a NON-LOCAL list with
     pairs between imported zones -- i-clusters that are not home clusters, as stock mdrun's search gives the kernel
-    under domain decomposition.  Lists from the host builder (the device search pairs home i-clusters only)."""
+    under domain decomposition.  Grids and lists from the device search (nbnxn_hip_make_pairlist_zones), checked against
+    the host builder's by SlabRun."""
     with mp.Manager() as m:
         ret = m.dict()
         _watch(mp.spawn(_worker, args=(1, _free_port(), "spce", True, ret, "nccl", True, (1, 1, 1), self_dims, "eighth"), nprocs=1, join=False))
+        r = ret[0]
+    assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
+    assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
+    assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
+    assert r["vir_err"] < 1e-5, r
+
+
+@pytest.mark.parametrize("self_dims,backend,rccl_direct", [((0, 1, 2), "nccl", True), ((0, 1), "nccl", True), ((0, 1, 2), "gloo", False)])
+def test_staged_pulses_one_rank(self_dims, backend, rccl_direct):
+    """The reference's staged pulses (dd_move_x / dd_move_f, domdec.c:667-870): one pulse per cut dimension, the later
+    ones forwarding the zones the earlier ones brought, forces back in reverse order -- through the module's phases
+    (nbnxn_hip_dd_set_phases) over RCCL, and through its per-pulse pack / unpack kernels with torch.distributed carrying
+    the messages.  Same zones and lists as the eighth shell with direct messages; coordinates that moved are forwarded
+    in the same step."""
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_worker, args=(1, _free_port(), "spce", True, ret, backend, rccl_direct, (1, 1, 1), self_dims, "staged"), nprocs=1, join=False))
         r = ret[0]
     assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
     assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
@@ -370,6 +388,43 @@ def _rccl_direct_worker(rank, port, ret):
                 ok = ok and np.abs(o[2 + 3 * si:5 + 3 * si] - seg.sum(0)).max() < 1e-6 * np.abs(seg).sum()
                 o[2 + 3 * si:5 + 3 * si] = 0
         ok = ok and not o.any()
+        # phases (nbnxn_hip_dd_set_phases, the reference's staged pulses): message B forwards 50 of the slots message A
+        # fills, in the same exchange; forces come back through B first, then through A
+        perm = rng.permutation(p.natoms).astype(np.int32)
+        s_a, r_a, s_b_home, r_b = perm[:100], perm[100:200], perm[200:230], perm[300:380]
+        s_b = np.concatenate([r_a[:50], s_b_home])
+        sh_a, sh_b = np.array([0.25, 0, 0], np.float32), np.array([0, 1.75, 0], np.float32)
+        nb.dd_set_messages([(0, 0, 100, 100, 23, sh_a), (0, 0, 80, 80, 27, sh_b)], np.concatenate([s_a, s_b]), np.concatenate([r_a, r_b]))
+        nb.dd_set_phases([1, 2])
+        nb.upload_xq(p.xq)
+        nb.clear_outputs(abi.FORCE_VIRIAL)
+        nb.wait_gpu(0)
+        nb.dd_move_x()
+        torch.cuda.synchronize()
+        want = p.xq.copy()
+        want[r_a, :3] = p.xq[s_a, :3] + sh_a
+        want[r_a, 3] = p.xq[s_a, 3]
+        want[r_b, :3] = want[s_b, :3] + sh_b
+        want[r_b, 3] = want[s_b, 3]
+        ok = ok and np.array_equal(xq_t.cpu().numpy(), want)
+        f_t.copy_(torch.from_numpy(f0))
+        torch.cuda.synchronize()
+        nb.dd_move_f()
+        torch.cuda.synchronize()
+        wantf = f0.copy()
+        wantf[s_b] += f0[r_b]
+        wantf[s_a] += wantf[r_a]
+        ok = ok and np.array_equal(f_t.cpu().numpy(), wantf)
+        o = torch.as_tensor(_DevArray(nb.output_slots()[0], (nslots * stride,)), device="cuda:0").cpu().numpy().astype(np.float64)
+        for si, rows in ((27, f0[r_b]), (23, wantf[r_a])):
+            ok = ok and np.abs(o[2 + 3 * si:5 + 3 * si] - rows.astype(np.float64).sum(0)).max() < 1e-6 * np.abs(rows).sum()
+            o[2 + 3 * si:5 + 3 * si] = 0
+        ok = ok and not o.any()
+        for bad in ([2], [1, 1], [2, 1], [1, 2, 3], []):
+            try:
+                nb.dd_set_phases(bad)
+            except g.gpu.HipError:
+                refused += 1
         try:
             nb.dd_set_messages([(0, 0, 1, 1, -1, (0, 0, 0))] * 14, np.zeros(14, np.int32), np.zeros(14, np.int32))   # too many
         except g.gpu.HipError:
@@ -390,7 +445,7 @@ def test_module_rccl_path_single_rank():
     with mp.Manager() as m:
         ret = m.dict()
         _watch(mp.spawn(_rccl_direct_worker, args=(_free_port(), ret), nprocs=1, join=False))
-        assert ret["ok"] and ret["refused"] == 5
+        assert ret["ok"] and ret["refused"] == 9
 
 
 def test_bench_starts_its_own_ranks_and_cuts_one_box():
