@@ -2007,7 +2007,7 @@ int nbnxn_hip_dd_move_f(nbnxn_hip_ptr_t nb)
             if (m.n_send > 0) { RCCL_TRY(g_rccl.Recv(nb->dd_f_in.p + (size_t)nb->dd_send_off[k] * 3, (size_t)m.n_send * 3, ncclFloat, m.send_to, nb->dd_comm, st)); }
         }
         RCCL_TRY(g_rccl.GroupEnd());
-        // into accumulation slot 0 of the output in use for the messages that crossed a periodic boundary
+        // into the accumulation slots of the output in use for the messages that crossed a periodic boundary
         HIP_TRY(nbx_launch_halo_unpack_f_msgs(nb->dd_send_slots.p + R.s0, R.s1 - R.s0, nb->dd_f_in.p + (size_t)R.s0 * 3, nb->f.p,
                                               nb->dd_send_wave_msg.p + R.s0 / 64, reinterpret_cast<const float4 *>(nb->dd_msg_shift.p), nb->out, st));
     }

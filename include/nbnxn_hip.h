@@ -587,7 +587,7 @@ int nbnxn_hip_halo_unpack_x(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const
 int nbnxn_hip_halo_pack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, float *d_buf, int iloc);
 /* owner's side: f[d_slots[i]] += d_buf[i] (atomic, the force kernels may still be running);
  * shift_index >= 0: the sum of d_buf is also added to that entry of the shift forces of the
- * output in use (accumulation slot 0), shift_index -1: not. */
+ * output in use (one of its accumulation slots), shift_index -1: not. */
 int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const float *d_buf, int shift_index, int iloc);
 /* everything put on the stream of iloc_waits from here on runs after what the stream of
  * iloc_done holds now (two pre-made events, no allocation); a no-op on one-stream handles */

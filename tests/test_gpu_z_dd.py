@@ -349,8 +349,8 @@ def _rccl_direct_worker(rank, port, ret):
         wantf = f0.copy()
         wantf[send] += f0[recv]
         ok = ok and np.array_equal(f_t.cpu().numpy(), wantf)
-        o = out_t.cpu().numpy()
-        got = o[2 + 3 * 17:5 + 3 * 17].astype(np.float64)
+        o = out_t.cpu().numpy().astype(np.float64).reshape(nslots, stride).sum(0)      # the shift forces land in any of the slots
+        got = o[2 + 3 * 17:5 + 3 * 17]
         ok = ok and np.abs(got - f0[recv].astype(np.float64).sum(0)).max() < 1e-6 * np.abs(f0[recv]).sum()
         o[2 + 3 * 17:5 + 3 * 17] = 0
         ok = ok and not o.any()
@@ -381,6 +381,7 @@ def _rccl_direct_worker(rank, port, ret):
         wantf[send] += f0[recv]
         ok = ok and np.array_equal(f_t.cpu().numpy(), wantf)
         o = torch.as_tensor(_DevArray(nb.output_slots()[0], (nslots * stride,)), device="cuda:0").cpu().numpy().astype(np.float64)
+        o = o.reshape(nslots, stride).sum(0)
         start = np.concatenate([[0], np.cumsum(counts)])
         for k, si in enumerate(sidx):
             if si >= 0:
@@ -416,6 +417,7 @@ def _rccl_direct_worker(rank, port, ret):
         wantf[s_a] += wantf[r_a]
         ok = ok and np.array_equal(f_t.cpu().numpy(), wantf)
         o = torch.as_tensor(_DevArray(nb.output_slots()[0], (nslots * stride,)), device="cuda:0").cpu().numpy().astype(np.float64)
+        o = o.reshape(nslots, stride).sum(0)
         for si, rows in ((27, f0[r_b]), (23, wantf[r_a])):
             ok = ok and np.abs(o[2 + 3 * si:5 + 3 * si] - rows.astype(np.float64).sum(0)).max() < 1e-6 * np.abs(rows).sum()
             o[2 + 3 * si:5 + 3 * si] = 0
