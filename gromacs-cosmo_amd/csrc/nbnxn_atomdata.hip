@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(64) nbnxn_halo_pack_f(const int *__restrict__ 
 }
 
 // The force kernels may still be adding to f on the other stream: atomic adds (one address per
-// thread, no contention).  WRAP: wave sum in double, one float atomic per wave and component.
+// thread, no contention).  WRAP: wave sum, one float atomic per wave and component into one of the 64 accumulation
+// slots (fshift_entry points into slot 0; the waves spread over the slots, see nbnxn_halo_unpack_f_msgs).
 template <bool WRAP>
 __global__ void __launch_bounds__(64) nbnxn_halo_unpack_f(const int *__restrict__ slot, int n, const float *__restrict__ buf,
                                                            float *__restrict__ f, float *__restrict__ fshift_entry)
@@ -101,18 +102,18 @@ __global__ void __launch_bounds__(64) nbnxn_halo_unpack_f(const int *__restrict_
     }
     if (WRAP)
     {
-        double dx = fx, dy = fy, dz = fz;
         for (int o = 32; o > 0; o >>= 1)
         {
-            dx += __shfl_down(dx, o);
-            dy += __shfl_down(dy, o);
-            dz += __shfl_down(dz, o);
+            fx += __shfl_down(fx, o);
+            fy += __shfl_down(fy, o);
+            fz += __shfl_down(fz, o);
         }
         if (threadIdx.x == 0)
         {
-            atomicAdd(fshift_entry + 0, (float)dx);
-            atomicAdd(fshift_entry + 1, (float)dy);
-            atomicAdd(fshift_entry + 2, (float)dz);
+            float *entry = fshift_entry + (size_t)(blockIdx.x % NBX_OUT_SLOTS) * NBX_OUT_STRIDE;
+            atomicAdd(entry + 0, fx);
+            atomicAdd(entry + 1, fy);
+            atomicAdd(entry + 2, fz);
         }
     }
 }

@@ -1673,7 +1673,7 @@ int nbnxn_hip_halo_unpack_f(nbnxn_hip_ptr_t nb, const int *d_slots, int n, const
     if (check_halo(nb, d_slots, n, d_buf, iloc)) { return 1; }
     if (shift_index < -1 || shift_index >= 45) { return nbx_fail("shift index %d outside [-1, 45)", shift_index); }
     HIP_TRY(hipSetDevice(nb->device));
-    // accumulation slot 0 of the output in use: {e_lj, e_el, fshift[45][3]}
+    // the entry in accumulation slot 0 of the output in use, {e_lj, e_el, fshift[45][3]}; the kernel's waves spread over the slots
     float *entry = shift_index >= 0 ? nb->out + 2 + 3 * shift_index : nullptr;
     HIP_TRY(nbx_launch_halo_unpack_f(d_slots, n, d_buf, nb->f.p, entry, nb->stream[nb->two_streams ? iloc : 0]));
     return 0;
