@@ -806,8 +806,35 @@ class SlabRun:
         self.exchange_beside_local = nb.reserved_cus() > 0 and os.environ.get("NBNXN_DD_X_FIRST") != "1"
         self.one_call = os.environ.get("NBNXN_DD_STEP_CALLS") != "many"
         if rccl_direct:
-            self.halo = RcclHalo(nb, dom, self.dev)
-        else:
+            # The module's communicator and its first exchange, checked: the exchange must bring exactly the coordinates
+            # the set-up brought through torch.distributed.  A rank whose RCCL call returns an error, or whose halo comes
+            # out different, takes every rank back to torch.distributed (the ranks agree first).
+            ok = 1
+            try:
+                self.halo = RcclHalo(nb, dom, self.dev)
+                slots = self.halo.halo_slots
+                want = self.xq_t[slots].clone()
+                self.xq_t[slots, :3] = 1e6
+                torch.cuda.synchronize(self.dev)          # torch's stream wrote; the module's non-local stream exchanges
+                self.halo.send_x()
+                torch.cuda.synchronize(self.dev)
+                if not torch.equal(self.xq_t[slots], want):
+                    ok = 0
+                    self.xq_t[slots] = want
+                    print(f"rank {rank}: the module's first halo exchange over RCCL brought other coordinates than the set-up; "
+                          "using torch.distributed", file=sys.stderr, flush=True)
+            except gpu.HipError as err:
+                ok = 0
+                print(f"rank {rank}: the module's RCCL exchange failed ({err}); using torch.distributed", file=sys.stderr, flush=True)
+            t = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if not int(t.item()):
+                try:
+                    nb.dd_finish()
+                except gpu.HipError:
+                    pass
+                self.rccl_direct = rccl_direct = False
+        if not rccl_direct:
             make = (lambda d: DeviceHalo(nb, d, self.dev)) if device_halo else (lambda d: HaloExchange(d, self.xq_t, self.f_t))
             self.halo = StagedHalo(make, dom) if dom.scheme == "staged" else make(dom)
         self.s_loc = torch.cuda.ExternalStream(nb.stream(abi.LOCAL), device=self.dev)

@@ -1,11 +1,11 @@
-"""SlabRun (the bench.py --gpus N path) rehearsed on ONE GPU: two ranks share cuda:0 and talk
-over gloo (dd.py stages device tensors through the host for gloo; RCCL needs one GPU per
-rank).  Covers what the CPU test cannot: the HIP module's buffers aliased as torch tensors,
-local + non-local lists on two HIP streams, the resident per-step sequence.
+"""The decomposed step on the GPU in ONE process: a rank that is its own neighbour in one to three dimensions carries
+the whole step -- local + non-local lists on two HIP streams, the halo kernels, real RCCL sends / receives (to itself)
+issued by the module or by torch.distributed, the slot reduction, half shell / eighth shell / staged pulses -- and the
+module's exchange calls are checked row by row.  The two-process rehearsals (two ranks sharing the card over gloo) are
+in test_zy_two_ranks_one_gpu.py, which borrows _worker and _watch from here.
 
-Collected after the single-process GPU tests on purpose (file name): it is the only GPU test that
-starts other processes, and it watches them with a deadline of its own, so that a stuck rank ends
-as a failure with the ranks' stacks on record (gpurun_out/dd_hang_rank*.txt) instead of a hang."""
+Worker processes are watched with a deadline, so that a stuck rank ends as a failure with the ranks' stacks on record
+(gpurun_out/dd_hang_rank*.txt) instead of a hang."""
 import os
 import sys
 import time
@@ -113,20 +113,6 @@ def _watch(ctx):
             pytest.fail(f"ranks {alive} still running after {DEADLINE_S} s; their stacks are in gpurun_out/dd_hang_rank*.txt")
 
 
-@pytest.mark.parametrize("model,device_halo", [("spc", True), ("spce", True), ("spce", False)])
-def test_slabrun_two_ranks_one_gpu(model, device_halo):
-    with mp.Manager() as m:
-        ret = m.dict()
-        ctx = mp.spawn(_worker, args=(2, _free_port(), model, device_halo, ret), nprocs=2, join=False)
-        _watch(ctx)
-        res = [ret[r] for r in range(2)]
-    for r in res:
-        assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
-        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
-        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
-        assert r["vir_err"] < 1e-5, r
-
-
 @pytest.mark.parametrize("reserve_cus", ["default", "0"])
 @pytest.mark.parametrize("model,rccl_direct", [("spce", True), ("spc", True), ("spce", False)])
 def test_slabrun_one_rank_over_rccl(model, rccl_direct, reserve_cus, monkeypatch):
@@ -152,41 +138,6 @@ def test_slabrun_one_rank_over_rccl(model, rccl_direct, reserve_cus, monkeypatch
     assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
     assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
     assert r["vir_err"] < 1e-5, r
-
-
-def test_load_balanced_slabs_two_ranks_one_gpu():
-    """A liquid film under thin vapour on two z slabs: the cut plane moved by the reference's balancing rule on the
-    ranks' cluster-pair counts (dd.balance_domain; the rule itself and four ranks: tests/test_dd_cpu.py), then the
-    decomposed step on the device with the grids and lists of the unequal slabs made by the device search."""
-    with mp.Manager() as m:
-        ret = m.dict()
-        _watch(mp.spawn(_worker, args=(2, _free_port(), "spce", True, ret, "gloo", False, (1, 1, 2), (), "half", 24, (0.4, 6)), nprocs=2, join=False))
-        res = [ret[r] for r in range(2)]
-    h = res[0]["history"]
-    loads = [r["load"] for r in res]
-    assert h[0] > 0.5 and max(loads) / (sum(loads) / 2) - 1 < 0.1, (h, loads)
-    for r in res:
-        assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
-        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
-        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
-        assert r["vir_err"] < 1e-5, r
-
-
-def test_brickrun_two_ranks_cut_along_x_one_gpu():
-    """A cut along x instead of z, grid (2, 1, 1): two ranks share cuda:0 and talk over gloo; the search keeps its
-    periodic shifts in y and z only.  (Four ranks on ONE GPU are not rehearsed here: with four processes sharing the
-    card the fill on a rank's local stream was never scheduled in about half the runs, tools/dd_debug.py; bricks in
-    two and three dimensions are covered by the gloo tests on the CPU with 4, 6 and 8 ranks, tests/test_dd_cpu.py, and
-    on the GPU by the one-rank tests below, where the rank is its own neighbour in every cut dimension.)"""
-    with mp.Manager() as m:
-        ret = m.dict()
-        _watch(mp.spawn(_worker, args=(2, _free_port(), "spce", True, ret, "gloo", False, (2, 1, 1), ()), nprocs=2, join=False))
-        res = [ret[r] for r in range(2)]
-    for r in res:
-        assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
-        assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
-        assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
-        assert r["vir_err"] < 1e-5, r
 
 
 @pytest.mark.parametrize("self_dims,rccl_direct", [((0, 1, 2), True), ((1, 2), True), ((0, 1, 2), False)])
@@ -448,31 +399,3 @@ def test_module_rccl_path_single_rank():
         ret = m.dict()
         _watch(mp.spawn(_rccl_direct_worker, args=(_free_port(), ret), nprocs=1, join=False))
         assert ret["ok"] and ret["refused"] == 9
-
-
-def test_bench_starts_its_own_ranks_and_cuts_one_box():
-    """`python bench.py --gpus 2 ... --strong` as the driver types it (no launcher): the script starts its two ranks
-    itself, before it touches the GPU, and cuts ONE box into two slabs (BASELINE configs[3] in small); with a
-    preconditioning phase, whose length rank 0's clock decides for both ranks.  On this
-    one-GPU box both ranks share cuda:0 over gloo (BENCH_REHEARSAL=1): the plumbing is what is checked, not a number."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["BENCH_REHEARSAL"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--tiles", "2,2,4", "--strong", "--steps", "3",
-                        "--warmup", "1", "--precondition", "0.2"], env=env, capture_output=True, text=True, timeout=280)
-    assert r.returncode == 0, r.stderr[-800:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
-    assert "10368 atoms" in d["config"]["workload"] and "cut into 2 z slabs" in d["config"]["workload"]
-    # the same box on one rank, no launcher either: the two ranks together hold the same list
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--tiles", "2,2,4", "--strong", "--steps", "3",
-                         "--warmup", "1", "--precondition", "0", "--no-cpu"], env=env, capture_output=True, text=True, timeout=280)
-    assert r1.returncode == 0, r1.stderr[-800:]
-    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
-    assert d1["n_gpus"] == 1 and "10368 atoms" in d1["config"]["workload"]
-    assert abs(d["config"]["pair_slots_per_step"] - d1["config"]["pair_slots_per_step"]) < 0.02 * d1["config"]["pair_slots_per_step"]
