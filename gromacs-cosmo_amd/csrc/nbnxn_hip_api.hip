@@ -140,6 +140,7 @@ struct nbnxn_hip {
     int         device = 0;
     bool        two_streams = false;
     int         reserved_cus = 0;   // CUs the local stream leaves to the non-local stream's work (CU mask)
+    bool        nonlocal_high_priority = true;   // priority of the non-local stream (GMX_HIP_NB_NONLOCAL_PRIORITY)
     hipStream_t stream[2] = {nullptr, nullptr};
     hipEvent_t  misc_ops_done = nullptr, nonlocal_done = nullptr;
     hipEvent_t  stream_mark[2] = {nullptr, nullptr};   // nbnxn_hip_stream_wait
@@ -814,10 +815,23 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     }
     if (nb->two_streams)
     {
-        // the non-local work sits on the critical path of the halo exchange: high priority
+        // The reference gives the non-local stream the high priority (nbnxn_cuda_data_mgmt.cu:569-594).  Here BOTH
+        // streams get the normal one: the two streams wait for each other through hipStreamWaitEvent, which is a
+        // barrier packet at the head of a hardware queue, and when several processes share the GPU a queue of HIGHER
+        // priority parked on such a packet starved the lower-priority queue it was waiting for -- for good (round 3,
+        // tools/stall_ab.sh with four processes on one GPU: non-local high, local normal: the local stream's first
+        // operation never ran, 1 run of 1 and about half the runs of round 2; non-local LOW: the mirror image, the
+        // non-local stream never ran, run 4; both normal: 10 of 10 runs clean).  The CU-masked local stream cannot be
+        // given a priority (hipExtStreamCreateWithCUMask takes none), so equal means normal.  DESIGN section 6.
+        // GMX_HIP_NB_NONLOCAL_PRIORITY=high|low|normal overrides (one process per GPU never showed the stall).
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&nb->stream[1], hipStreamNonBlocking, hi));
+        const char *prio = getenv("GMX_HIP_NB_NONLOCAL_PRIORITY");
+        nb->nonlocal_high_priority = prio ? (strcmp(prio, "high") == 0) : false;
+        // hipDeviceGetStreamPriorityRange gives {least, greatest} = {1, -1} here: low, NORMAL = 0 in between, high
+        int pr = nb->nonlocal_high_priority ? hi : (lo + hi) / 2;
+        if (prio && strcmp(prio, "low") == 0) { pr = lo; }
+        HIP_TRY(hipStreamCreateWithPriority(&nb->stream[1], hipStreamNonBlocking, pr));
         HIP_TRY(hipEventCreateWithFlags(&nb->misc_ops_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&nb->stream_mark[0], hipEventDisableTiming));

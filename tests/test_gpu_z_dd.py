@@ -1,8 +1,8 @@
 """The decomposed step on the GPU in ONE process: a rank that is its own neighbour in one to three dimensions carries
 the whole step -- local + non-local lists on two HIP streams, the halo kernels, real RCCL sends / receives (to itself)
 issued by the module or by torch.distributed, the slot reduction, half shell / eighth shell / staged pulses -- and the
-module's exchange calls are checked row by row.  The two-process rehearsals (two ranks sharing the card over gloo) are
-in test_zy_two_ranks_one_gpu.py, which borrows _worker and _watch from here.
+module's exchange calls are checked row by row.  The rehearsals with two and four processes sharing the card over gloo
+are in test_gpu_dd_ranks_one_gpu.py, which borrows _worker and _watch from here.
 
 Worker processes are watched with a deadline, so that a stuck rank ends as a failure with the ranks' stacks on record
 (gpurun_out/dd_hang_rank*.txt) instead of a hang."""
@@ -47,6 +47,9 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
         run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
                          rccl_direct=rccl_direct, grid=grid, self_dims=self_dims, scheme=scheme, balance=balance, film=film)
         dom = run.dom
+        # a test that asks for the module's own RCCL path must get it: the fall-back to torch.distributed is for
+        # production runs, here it would hide a broken nbnxn_hip_dd_* path behind a line on stderr
+        assert run.rccl_direct == rccl_direct, "the module's RCCL path fell back to torch.distributed"
         assert len(dom.msgs) == {"half": {1: 1, 2: 4, 3: 13}, "eighth": {1: 1, 2: 3, 3: 7}, "staged": {1: 1, 2: 2, 3: 3}}[scheme][sum(dom.decomp)]
         # wreck the imported coordinates on the device: the step has to bring them back
         run.xq_t[run.halo.halo_slots, :3] = 1e6
