@@ -98,13 +98,14 @@ struct PList {
 // ---- the entry point that allocates nothing (nbnxn_hip_launch_kernel_noalloc) ----
 // Its kernels need the same scratch buffer the other launches get from the handle's allocation: the NBX_OUT_SLOTS
 // partial-sum slots {e_lj, e_el, fshift[45][3]} that the waves add into and a fold kernel sums.  Here they live in a
-// file-scope device array: 64 x 144 floats = 36,864 bytes, whatever the system size, held by every GPU the library
-// runs on until the process ends.  `scratch` is a host-side stand-in for the symbol, NOT a device address: host
-// code only ever uses the per-device address hipGetSymbolAddress returned (g_scratch_ptr), as kernel argument and
-// for the clearing fill.
+// file-scope device array: 2 x 64 x 144 floats = 73,728 bytes, whatever the system size, held by every GPU the library
+// runs on until the process ends; the local and the non-local launch of a two-stream handle each use their own half,
+// so the two may overlap (they run on different streams in the decomposed step).  `scratch` is a host-side stand-in
+// for the symbol, NOT a device address: host code only ever uses the per-device address hipGetSymbolAddress returned
+// (g_scratch_ptr), as kernel argument and for the clearing fill.
 #define NBX_NOALLOC_SCRATCH_FLOATS (NBX_OUT_SLOTS * NBX_OUT_STRIDE)
 #define NBX_MAX_DEVICES 64
-static __device__ __align__(256) float scratch[NBX_NOALLOC_SCRATCH_FLOATS];
+static __device__ __align__(256) float scratch[2 * NBX_NOALLOC_SCRATCH_FLOATS];
 
 namespace {
 float     *g_scratch_ptr[NBX_MAX_DEVICES] = {};   // each GPU has its own copy of the array at its own address
@@ -1161,10 +1162,17 @@ int nbnxn_hip_launch_kernel_noalloc(nbnxn_hip_ptr_t nb, int flags, int iloc, int
     {
         return nbx_fail("launch_kernel_noalloc: %d list entries exceed the maximum of %d this entry point takes", pl.nsci, NBX_NOALLOC_MAX_NSCI);
     }
-    float *slots = g_scratch_ptr[nb->device];
-    if (!slots) { return nbx_fail("launch_kernel_noalloc: the scratch array of device %d was never bound", nb->device); }
+    if (!g_scratch_ptr[nb->device]) { return nbx_fail("launch_kernel_noalloc: the scratch array of device %d was never bound", nb->device); }
+    float *slots = g_scratch_ptr[nb->device] + (size_t)iloc * NBX_NOALLOC_SCRATCH_FLOATS;   // a half per locality
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = nb->stream[iloc];
+    // the ordering launch_impl keeps (nbnxn_cuda.cu:325-337): the non-local launch starts after whatever the local
+    // stream held when the local launch was issued (clears, coordinate copies)
+    if (nb->two_streams)
+    {
+        if (iloc == NBX_LOCAL) { HIP_TRY(hipEventRecord(nb->misc_ops_done, st)); }
+        else { HIP_TRY(hipStreamWaitEvent(st, nb->misc_ops_done, 0)); }
+    }
 
     nbx_kernel_args_t a;
     a.xq = reinterpret_cast<const float4 *>(d_xq); a.f = d_f; a.type = nb->type.p; a.shift_vec = nb->shift_vec; a.ntype = nb->ntype;
@@ -1877,8 +1885,12 @@ int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message
     if (!nb->xq.p || !nb->f.p) { return nbx_fail("dd_set_messages before the atom data exists"); }
     // padded layouts: every message starts at a multiple of 64 rows, so that one wave of the pack / unpack kernels
     // belongs to one message
+    // Everything is validated and laid out in locals first and only copied into the handle once the device arrays
+    // hold it: a rejected call leaves the installed messages as they were (the Python binding runs with abort-on-error
+    // off and goes on after a failure).
     std::vector<int> h_send, h_recv, h_wave;
     std::vector<float> h_shift((size_t)nmsg * 4);
+    std::vector<int> send_off(nmsg), recv_off(nmsg);
     size_t si = 0, ri = 0;
     for (int k = 0; k < nmsg; k++)
     {
@@ -1892,7 +1904,7 @@ int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message
             return nbx_fail("dd_set_messages: message %d moves %d / %d halo atoms on a grid of %d slots", k, m.n_send, m.n_recv, nb->natoms);
         }
         if (m.shift_index < -1 || m.shift_index >= NBX_SHIFTS) { return nbx_fail("dd_set_messages: shift index %d outside [-1, %d)", m.shift_index, NBX_SHIFTS); }
-        nb->dd_send_off[k] = (int)h_send.size(); nb->dd_recv_off[k] = (int)h_recv.size();
+        send_off[k] = (int)h_send.size(); recv_off[k] = (int)h_recv.size();
         for (int i = 0; i < m.n_send; i++, si++)
         {
             if (send_slots[si] < 0 || send_slots[si] >= nb->natoms) { return nbx_fail("dd_set_messages: send slot %d outside the grid", send_slots[si]); }
@@ -1909,7 +1921,6 @@ int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message
         int is = m.shift_index;
         memcpy(&h_shift[4 * k], m.shift, 3 * sizeof(float));
         memcpy(&h_shift[4 * k + 3], &is, sizeof(int));
-        nb->dd_msg[k] = m;
     }
     HIP_TRY(hipSetDevice(nb->device));
     hipStream_t st = dd_stream(nb, NBX_NONLOCAL);
@@ -1919,11 +1930,15 @@ int nbnxn_hip_dd_set_messages(nbnxn_hip_ptr_t nb, int nmsg, const nbx_dd_message
         || dev_reserve(nb->dd_x_out, ns * 4) || dev_reserve(nb->dd_x_in, nr * 4) || dev_reserve(nb->dd_f_out, nr * 3) || dev_reserve(nb->dd_f_in, ns * 3)) { return 1; }
     // the steps in flight still read the old lists
     HIP_TRY(hipStreamSynchronize(st));
+    // from here on the device arrays change: the old messages are gone whatever happens, so no exchange may run on a
+    // half-written set if an upload fails
+    nb->dd_nmsg = 0; nb->dd_nphase = 0;
     if (!h_send.empty()) { HIP_TRY(hipMemcpyAsync(nb->dd_send_slots.p, h_send.data(), h_send.size() * sizeof(int), hipMemcpyHostToDevice, st)); }
     if (!h_recv.empty()) { HIP_TRY(hipMemcpyAsync(nb->dd_recv_slots.p, h_recv.data(), h_recv.size() * sizeof(int), hipMemcpyHostToDevice, st)); }
     if (!h_wave.empty()) { HIP_TRY(hipMemcpyAsync(nb->dd_send_wave_msg.p, h_wave.data(), h_wave.size() * sizeof(int), hipMemcpyHostToDevice, st)); }
     HIP_TRY(hipMemcpyAsync(nb->dd_msg_shift.p, h_shift.data(), h_shift.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < nmsg; k++) { nb->dd_send_off[k] = send_off[k]; nb->dd_recv_off[k] = recv_off[k]; nb->dd_msg[k] = msg[k]; }
     nb->dd_send_rows = (int)h_send.size(); nb->dd_recv_rows = (int)h_recv.size();
     nb->dd_nmsg = nmsg;
     nb->dd_nphase = 1; nb->dd_phase_end[0] = nmsg;      // all at once until nbnxn_hip_dd_set_phases says otherwise

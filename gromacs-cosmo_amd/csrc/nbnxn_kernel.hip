@@ -16,15 +16,25 @@
 //     accumulation slots (slot = entry index mod slots), so no long same-address fp32 atomic
 //     chain builds up; the host folds the slots in double precision after the copy-back.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "nbnxn_kernel.h"
 
 #ifdef NBX_TIMELINE
-// debug builds only (make timeline): per list entry {start, end} in 100 MHz ticks and the hardware id of the wave
-__device__ unsigned long long nbx_timeline[3 * 65536];
-extern "C" int nbnxn_hip_debug_timeline(unsigned long long *out, int n)
+// debug builds only (make timeline): per list entry {start, first pair, last pair done, end} in 100 MHz ticks and the
+// hardware id of the wave with the entry's group count
+#define NBX_TL_WORDS 6
+#if NBX_UNIT_EL == 0
+#define NBX_TL_SYM nbx_timeline_rf
+#define NBX_TL_FN nbnxn_hip_debug_timeline_rf
+#else
+#define NBX_TL_SYM nbx_timeline
+#define NBX_TL_FN nbnxn_hip_debug_timeline
+#endif
+__device__ unsigned long long NBX_TL_SYM[NBX_TL_WORDS * 65536];
+extern "C" int NBX_TL_FN(unsigned long long *out, int n)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbx_timeline), sizeof(unsigned long long) * 3 * (size_t)(n < 65536 ? n : 65536)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(NBX_TL_SYM), sizeof(unsigned long long) * NBX_TL_WORDS * (size_t)(n < 65536 ? n : 65536)) == hipSuccess ? 0 : 1;
 }
 #endif
 
@@ -36,6 +46,50 @@ __device__ nbx_f32x4 nbx_buffer_load_f32x4(nbx_i32x4 rsrc, int voffset, int soff
 __device__ int       nbx_buffer_load_i32(nbx_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 // v_writelane_b32: lane `lane` of the result is val, the others keep old
 __device__ int       nbx_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+#ifndef NBX_KERNEL_WAVES
+#define NBX_KERNEL_WAVES 4
+#endif
+#ifndef NBX_KERNEL_WAVES_F
+#define NBX_KERNEL_WAVES_F 4
+#endif
+#ifndef NBX_ZERO_AT_END
+#define NBX_ZERO_AT_END 1
+#endif
+#ifndef NBX_HDR2
+#define NBX_HDR2 1     // the cj4 group header is requested two groups ahead and decoded one group ahead
+#endif
+#ifndef NBX_PRO2
+#define NBX_PRO2 1     // the type-pair table is requested before anything else in the prologue
+#endif
+#ifndef NBX_FJ_CAP
+#define NBX_FJ_CAP 32
+#endif
+#ifndef NBX_JAHEAD3
+#define NBX_JAHEAD3 0
+#endif
+#ifndef NBX_CPAIR
+#define NBX_CPAIR 0
+#endif
+#ifndef NBX_JRED2
+#define NBX_JRED2 1
+#endif
+#ifndef NBX_XI_LDS
+#define NBX_XI_LDS 2     // i-atoms read from LDS per pair instead of held in 32 registers: 0 never, 1 always, 2 Ewald flavours
+#endif
+#ifndef NBX_KERNEL_WAVES_EW
+#define NBX_KERNEL_WAVES_EW 5    // waves per SIMD the Ewald flavours are compiled for (5 needs <= 96 registers)
+#endif
+constexpr bool xi_in_lds(int el) { return NBX_XI_LDS == 1 || (NBX_XI_LDS == 2 && el != NBX_EL_RF); }
+// (the global-table instantiations, more than 16 atom types, keep 4 waves: at 96 registers some of them spill)
+constexpr int  kernel_waves(int el, bool ener, bool lds_table)
+{
+    return el != NBX_EL_RF && NBX_XI_LDS == 2 && lds_table ? NBX_KERNEL_WAVES_EW : (ener ? NBX_KERNEL_WAVES : NBX_KERNEL_WAVES_F);
+}
+#if NBX_JAHEAD3 && !NBX_HDR2
+#error "NBX_JAHEAD3 needs the next group's header at the top of the iteration (NBX_HDR2)"
+#endif
+
 
 namespace {
 
@@ -423,6 +477,53 @@ __device__ __forceinline__ nbx_i32x4 make_rsrc(const void *p)
     return r;
 }
 
+// Ordering of LDS accesses between the lanes of ONE wave (the workgroup is one wave).  __syncthreads() would do, but
+// as a workgroup-scope fence it also drains every outstanding global operation (s_waitcnt vmcnt(0)): the j-force
+// atomics just issued, ~1-3 thousand cycles under load, several times per entry.  The LDS processes one wave's
+// instructions in order, so a write followed by a read needs no wait at all; what is needed is that the COMPILER keeps
+// the order, which a wavefront-scope fence does without emitting an instruction.
+#ifndef NBX_WAVE_SYNC
+#define NBX_WAVE_SYNC 1
+#endif
+__device__ __forceinline__ void wave_lds_sync()
+{
+#if NBX_WAVE_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __syncthreads();
+#endif
+}
+
+// a cj4 group as it lies in memory: w0 = cj[4], w1 = {imei[0].imask, imei[0].excl_ind, imei[1].imask, imei[1].excl_ind}
+struct nbx_jraw_t {
+    int4 w0, w1;
+};
+
+__device__ __forceinline__ void load_jraw(const nbx_kernel_view_t &a, int j4, nbx_jraw_t &r)
+{
+    // the whole 32-byte group in one scalar load
+    const int4 *g = reinterpret_cast<const int4 *>(a.cj4 + j4);
+    r.w0 = g[0];
+    r.w1 = g[1];
+}
+
+__device__ __forceinline__ void decode_jhdr(const nbx_kernel_view_t &a, const nbx_jraw_t &r, int lane, nbx_jhdr_t &h)
+{
+    // slots without interaction bits hold undefined j-clusters (nbnxn_search.c:2460-2472): cluster 0 is read for them
+    const int4 w0 = r.w0, w1 = r.w1;
+    h.imask = (unsigned)w1.x | (unsigned)w1.z;
+    const int ei0 = w1.y, ei1 = w1.w;
+    // excl[0] is the shared all-ones entry (types/nbnxn_pairlist.h:197-199): no load for it
+    h.wexcl = 0xffffffffu;
+    if ((ei0 | ei1) != 0) { h.wexcl = a.excl[lane < 32 ? ei0 : ei1].pair[lane & 31]; }
+    h.cj[0] = (h.imask & 0x000000ffu) ? w0.x : 0;
+    h.cj[1] = (h.imask & 0x0000ff00u) ? w0.y : 0;
+    h.cj[2] = (h.imask & 0x00ff0000u) ? w0.z : 0;
+    h.cj[3] = (h.imask & 0xff000000u) ? w0.w : 0;
+}
+
 __device__ __forceinline__ void load_jhdr(const nbx_kernel_view_t &a, int j4, int lane, nbx_jhdr_t &h)
 {
     // the whole 32-byte group in one scalar load; slots without interaction bits hold undefined j-clusters
@@ -445,6 +546,9 @@ __device__ __forceinline__ void load_jslot(const nbx_jsrc_t &js, int cj, nbx_jsl
 {
     // buffer loads: the wave-uniform cluster offset rides in an SGPR, the lane's row offset is a constant VGPR --
     // no address arithmetic per j-cluster
+#ifdef NBX_DBG_JFIX      // timing experiments only (wrong forces): every j-cluster is one of clusters 0-3, always in L1
+    cj &= 3;
+#endif
     const nbx_f32x4 v = nbx_buffer_load_f32x4(js.rx, js.voff16, cj * 128, 0);
     s.x = make_float4(v.x, v.y, v.z, v.w);
     s.t = nbx_buffer_load_i32(js.rt, js.voff4, cj * 32, 0);
@@ -472,14 +576,23 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
                                             unsigned &imask, const bool central, const int sci, const int tidxi,
                                             const int tidxj, const char *ljt_lane, float *s_fj_lane,
                                             int &cjs, int &nfj, nbx_eacc_t &acc, const float ox, const float oy,
-                                            const float oz, const float r2inc)
+                                            const float oz, const float r2inc, const float4 *s_xi_lane)
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
     float2 c[8];
     float  cg[8];
     constexpr int  TS    = lds_entry_bytes(VMOD, ENER);
     constexpr bool THIRD = has_third(VMOD, ENER);
-    if (NBFP_LDS)
+#ifdef NBX_DBG_NOLJROWS   // timing experiments only (wrong forces): no LDS reads for the LJ rows
+    if (true)
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c[i] = make_float2(xi[i].w, xi[i].w * 0.5f); cg[i] = 0.0f; }
+    }
+    else
+#endif
+    if (NBFP_LDS && NBX_CPAIR && !THIRD) { }
+    else if (NBFP_LDS)
     {
         const char *row = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
         if (THIRD)
@@ -515,6 +628,10 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
             if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; cg[i] *= a.k.c6scale; }
         }
     }
+#if NBX_CPAIR
+    // experiment: the LJ entry of a pair is read when the pair is computed (2 live registers instead of 16)
+    const char *crow = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
+#endif
     float4 xj = s.x;
     // Ewald: scaled coordinates relative to the entry's origin, see the kernel
     if (EL != NBX_EL_RF) { xj.x = fmaf(xj.x, a.k.xscale, ox); xj.y = fmaf(xj.y, a.k.xscale, oy); xj.z = fmaf(xj.z, a.k.xscale, oz); }
@@ -527,17 +644,43 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = central && (cj == sci * 8 + i);
             bool       any  = true;
-            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xi[i], xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, r2inc,
+#if NBX_CPAIR
+            if (NBFP_LDS && !THIRD) { c[i] = *reinterpret_cast<const float2 *>(crow + 8 * i); cg[i] = 0.0f; }
+#endif
+            // Ewald flavours: the i-atoms stay in LDS and are read per pair (xi_in_lds)
+            const float4 xiv = xi_in_lds(EL) ? s_xi_lane[i * 8] : xi[i];
+            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xiv, xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, r2inc,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, acc, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
     }
+#if NBX_JRED2
+    // Sums over the 8 lanes of a j-atom, delivered as x / y / z to lanes 0 / 1 / 2 of the group.  x and y share ONE
+    // reduction tree: in the first step an even lane keeps its x and takes its neighbour's x, an odd lane keeps its y
+    // and takes its neighbour's y, so that after it even lanes carry x sums and odd lanes y sums; the two later steps
+    // (lane ^ 2, lane + 4) keep the parity.  6 cross-lane adds and 3 selects where three separate trees took 9 and 2
+    // (a DPP add costs the SIMD twice a plain instruction, tools/ubench/valu_mix.hip).
+    const bool  odd  = (tidxi & 1) != 0;
+    const float keep = odd ? fjy : fjx, give = odd ? fjx : fjy;
+    float       rxy  = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+    rxy = dpp_add<0x4E>(rxy);     // quad_perm [2,3,0,1]
+    rxy = dpp_add<0x104>(rxy);    // row_shl:4: lane k takes lane k + 4 (lanes 0 / 1 of the group complete x / y)
+    fjz = dpp_add<0xB1>(fjz);
+    fjz = dpp_add<0x4E>(fjz);
+    fjz = dpp_add<0x104>(fjz);    // lanes 0-3 of the group complete z
+    // keep the last reduction step out of the lane-masked store below: sunk in there, its cross-lane move
+    // can no longer be folded into the add (a DPP source lane must be active)
+    __asm__ volatile("" : "+v"(rxy), "+v"(fjz));
+    const float fj = tidxi == 2 ? fjz : rxy;
+    if (tidxi < 3) { s_fj_lane[nfj * 24] = fj; }
+#else
     fjx = reduce8(fjx); fjy = reduce8(fjy); fjz = reduce8(fjz);
     // keep the last reduction step out of the lane-masked store below: sunk in there, its cross-lane move
     // can no longer be folded into the add (a DPP source lane must be active)
     __asm__ volatile("" : "+v"(fjx), "+v"(fjy), "+v"(fjz));
     const float fj = tidxi == 0 ? fjx : (tidxi == 1 ? fjy : fjz);
     if (tidxi < 3) { s_fj_lane[nfj * 24] = fj; }
+#endif
     // the parked cluster's index goes into lane nfj of a register (one v_writelane, no LDS traffic, no exec change)
     cjs = nbx_writelane(cj, nfj, cjs);
     nfj++;
@@ -550,7 +693,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
 // flushed as full 64-lane atomic instructions; the kernel's loads then only wait for loads.
 __device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int cjs, int n, int lane)
 {
-    __syncthreads();
+    wave_lds_sync();
     // (the lane read takes place with every lane active: a cross-lane read from a lane that has left the loop returns 0)
     for (int base = 0; base < n * 24; base += 64)
     {
@@ -558,9 +701,13 @@ __device__ __forceinline__ void flush_fj(float *f, const float *s_fj, const int 
         const int cl   = (idx * 2731) >> 16;   // idx / 24 for idx < 4096
         const int comp = idx - cl * 24;
         const int cj   = __shfl(cjs, cl);
+#ifdef NBX_DBG_NO_JATOMICS      // timing experiments only (wrong forces): what the j-force atomics cost
+        if (idx < n * 24 && s_fj[idx] == 1.2345e33f) { atomicAdd(&f[(unsigned)(cj * 24 + comp)], s_fj[idx]); }
+#else
         if (idx < n * 24) { atomicAdd(&f[(unsigned)(cj * 24 + comp)], s_fj[idx]); }
+#endif
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // sum over the wave with DPP moves only (no LDS round trips); the result is valid in lanes 48..63
@@ -573,15 +720,8 @@ __device__ __forceinline__ float wave_sum_hi(float v)
     return v;
 }
 
-#ifndef NBX_KERNEL_WAVES
-#define NBX_KERNEL_WAVES 4
-#endif
-#ifndef NBX_KERNEL_WAVES_F
-#define NBX_KERNEL_WAVES_F 4
-#endif
-
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? NBX_KERNEL_WAVES : NBX_KERNEL_WAVES_F, 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_waves(EL, ENER, NBFP_LDS), 8))) nbnxn_kernel(NBX_KERNEL_PARAMS)
 {
     NBX_KERNEL_ARGS_FROM_PARAMS
     const int lane  = threadIdx.x;
@@ -592,7 +732,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
     __shared__ int    s_ti[NBFP_LDS ? 1 : 64];
     constexpr int     TS     = lds_entry_bytes(VMOD, ENER);
     constexpr int     ROW    = ljt_row_bytes(VMOD, ENER);
-    constexpr int     FJ_CAP = 32;
+    constexpr int     FJ_CAP = NBX_FJ_CAP;
     // j-force parking area; at the start of an entry it holds the staged LJ table (MAX_LDS_TYPES^2 x 12 bytes = 3 KB),
     // at its end the transposed i-forces
     __shared__ __attribute__((aligned(16))) float s_fj[FJ_CAP * 24];
@@ -604,15 +744,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
 
 #ifdef NBX_TIMELINE
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl_c0 = __builtin_amdgcn_s_memtime();
 #endif
-    const nbx_sci_t e     = a.sci[blockIdx.x];
-    const int       sci   = e.sci;
     const int       ntype = a.ntype;
+#if NBX_PRO2
+    // the type-pair table depends on nothing but the kernel arguments: requested first, it arrives while the entry,
+    // its first group and its i-atoms (three dependent round trips) are on their way
+    float2 st_c[(MAX_LDS_TYPES * MAX_LDS_TYPES + 63) / 64];
+    float  st_g[(MAX_LDS_TYPES * MAX_LDS_TYPES + 63) / 64];
+    if (NBFP_LDS)
+    {
+#pragma unroll
+        for (int m = 0; m < (MAX_LDS_TYPES * MAX_LDS_TYPES + 63) / 64; m++)
+        {
+            const int k = lane + 64 * m;
+            st_c[m] = make_float2(0.0f, 0.0f); st_g[m] = 0.0f;
+            if (k < ntype * ntype)
+            {
+                st_c[m] = a.nbfp[k];
+                if (VMOD == 3) { st_g[m] = a.c6grid[k]; }
+            }
+        }
+    }
+#endif
+#ifdef NBX_DBG_SAME_ENTRY   // timing experiments only: every wave walks one of the first 64 (largest) entries: everything in cache
+    const nbx_sci_t e     = a.sci[blockIdx.x & 63];
+#else
+    const nbx_sci_t e     = a.sci[blockIdx.x];
+#endif
+    const int       sci   = e.sci;
     const bool      central = (e.shift == NBX_CENTRAL);
 
+#if !NBX_ZERO_AT_END
     // in-kernel clear of the idle output buffer (nbnxn_hip_set_clear_in_kernel): the next step
     // accumulates into it, so no fill has to be dispatched between two steps
     for (int i = blockIdx.x * 64 + lane; i < p_zero_n4; i += gridDim.x * 64) { p_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#endif
 
     nbx_jsrc_t js;
     js.rx     = make_rsrc(a.xq);
@@ -626,6 +793,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
     cur.cj[0] = cur.cj[1] = cur.cj[2] = cur.cj[3] = 0;
     if (e.cj4_ind_start < e.cj4_ind_end) { load_jhdr(a, e.cj4_ind_start, lane, cur); }
     load_jslot(js, cur.cj[0], sa);
+#if NBX_JAHEAD3
+    nbx_jslot_t sc, sd;
+    load_jslot(js, cur.cj[1], sb);
+    load_jslot(js, cur.cj[2], sc);
+#endif
 
     int ti;
     {
@@ -642,6 +814,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
             // the type-pair table as it lies in memory ([ti][tj]), scaled, staged in the parking area
             float2 *stage  = reinterpret_cast<float2 *>(s_fj);
             float  *stage3 = s_fj + 2 * MAX_LDS_TYPES * MAX_LDS_TYPES;
+#if NBX_PRO2
+#pragma unroll
+            for (int m = 0; m < (MAX_LDS_TYPES * MAX_LDS_TYPES + 63) / 64; m++)
+            {
+                const int k = lane + 64 * m;
+                if (k < ntype * ntype)
+                {
+                    float2 c = st_c[m];
+                    if (EL != NBX_EL_RF) { c.x *= a.k.c6scale; c.y *= a.k.c12scale; }
+                    stage[k] = c;
+                    if (VMOD == 3) { stage3[k] = st_g[m] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
+                }
+            }
+#else
             for (int k = lane; k < ntype * ntype; k += 64)
             {
                 float2 c = a.nbfp[k];
@@ -649,10 +835,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
                 stage[k] = c;
                 if (VMOD == 3) { stage3[k] = a.c6grid[k] * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
             }
+#endif
         }
         else { s_ti[lane] = ti; }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     float c6ii = 0.0f;   // LJ-PME self term
     if (NBFP_LDS)
@@ -693,13 +880,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
     float4   xi[8];
     unsigned tlo = 0, thi = 0;
     float    fix[8], fiy[8], fiz[8];
+    if (xi_in_lds(EL) && EL != NBX_EL_RF)
+    {
+        // every lane scales the atom it staged; the pair loop reads the scaled rows
+        float4 x = s_xqi[lane];
+        x.x = fmaf(x.x, a.k.xscale, ox); x.y = fmaf(x.y, a.k.xscale, oy); x.z = fmaf(x.z, a.k.xscale, oz);
+        wave_lds_sync();
+        s_xqi[lane] = x;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++)
     {
-        xi[i] = s_xqi[i * 8 + tidxi];
-        if (EL != NBX_EL_RF)
+        if (xi_in_lds(EL)) { xi[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+        else
         {
-            xi[i].x = fmaf(xi[i].x, a.k.xscale, ox); xi[i].y = fmaf(xi[i].y, a.k.xscale, oy); xi[i].z = fmaf(xi[i].z, a.k.xscale, oz);
+            xi[i] = s_xqi[i * 8 + tidxi];
+            if (EL != NBX_EL_RF)
+            {
+                xi[i].x = fmaf(xi[i].x, a.k.xscale, ox); xi[i].y = fmaf(xi[i].y, a.k.xscale, oy); xi[i].z = fmaf(xi[i].z, a.k.xscale, oz);
+            }
         }
         if (!NBFP_LDS)
         {
@@ -727,25 +926,56 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
         }
     }
     // the per-entry table is complete and the staged copy no longer needed: the parking area is free
-    __syncthreads();
+    wave_lds_sync();
 
     const char *ljt_lane  = s_ljt + (TS == 8 ? tidxi * 64 + (tidxi >> 2) * 16 : tidxi * 144);
     float      *s_fj_lane = s_fj + tidxj * 3 + (tidxi < 3 ? tidxi : 0);
 
+#ifdef NBX_TIMELINE
+    const unsigned long long tl_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #define NBX_JCLUSTER(JM, SLOT)                                                                             \
     jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, ljt_lane, s_fj_lane, cjs,  \
-                                               nfj, acc, ox, oy, oz, r2inc_v)
+                                               nfj, acc, ox, oy, oz, r2inc_v, s_xqi + tidxi)
+#if NBX_HDR2
+    // the raw words of the group after the current one, requested a whole group ahead (zeros: no such group)
+    nbx_jraw_t raw1;
+    raw1.w0 = make_int4(0, 0, 0, 0); raw1.w1 = make_int4(0, 0, 0, 0);
+    if (e.cj4_ind_start + 1 < e.cj4_ind_end) { load_jraw(a, e.cj4_ind_start + 1, raw1); }
+#endif
     for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
     {
         // software pipeline: the next group's list words are requested before this group's
         // arithmetic starts, each j-cluster's atoms one j-cluster ahead
         nbx_jhdr_t nxt;
+#if NBX_HDR2
+        // A scalar load that is consumed right away (the exclusion word's address and the j-cluster indices hang on
+        // it) parks the wave for a scalar-cache or L2 round trip once per group.  So the group after next is REQUESTED
+        // here and the next group, requested one iteration ago, is decoded from registers (all-zero words give an
+        // empty group: no interaction bits, cluster 0, no exclusion word).
+        decode_jhdr(a, raw1, lane, nxt);
+        nbx_jraw_t raw2;
+        raw2.w0 = make_int4(0, 0, 0, 0); raw2.w1 = make_int4(0, 0, 0, 0);
+        if (j4 + 2 < e.cj4_ind_end) { load_jraw(a, j4 + 2, raw2); }
+#else
         nxt.imask = 0; nxt.wexcl = 0xffffffffu;
         nxt.cj[0] = nxt.cj[1] = nxt.cj[2] = nxt.cj[3] = 0;
         if (j4 + 1 < e.cj4_ind_end) { load_jhdr(a, j4 + 1, lane, nxt); }
+#endif
 
         unsigned imask = cur.imask;
+#if NBX_JAHEAD3
+        // experiment: j-atoms requested three j-clusters ahead (four rolling register sets)
+        load_jslot(js, cur.cj[3], sd);
+        NBX_JCLUSTER(0, sa);
+        load_jslot(js, nxt.cj[0], sa);
+        NBX_JCLUSTER(1, sb);
+        load_jslot(js, nxt.cj[1], sb);
+        NBX_JCLUSTER(2, sc);
+        load_jslot(js, nxt.cj[2], sc);
+        NBX_JCLUSTER(3, sd);
+#else
         load_jslot(js, cur.cj[1], sb);
         NBX_JCLUSTER(0, sa);
         load_jslot(js, cur.cj[2], sa);
@@ -754,6 +984,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
         NBX_JCLUSTER(2, sa);
         load_jslot(js, nxt.cj[0], sa);
         NBX_JCLUSTER(3, sb);
+#endif
 
         if (PRUNE)
         {
@@ -764,10 +995,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
             }
         }
         cur = nxt;
+#if NBX_HDR2
+        raw1 = raw2;
+#endif
         if (nfj > FJ_CAP - 4) { flush_fj(a.f, s_fj, cjs, nfj, lane); nfj = 0; }
     }
 #undef NBX_JCLUSTER
     if (nfj > 0) { flush_fj(a.f, s_fj, cjs, nfj, lane); }
+#ifdef NBX_TIMELINE
+    const unsigned long long tl_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // i-forces: every lane holds 24 partial sums (8 i-clusters x xyz) that have to be added over the 8 lanes sharing
     // an i-atom.  They go through LDS transposed, half of the i-clusters at a time (the j-force parking area is free
@@ -789,11 +1026,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
                 s_fj[(at * 3 + 1) * 8 + tidxj] = fiy[4 * h + k];
                 s_fj[(at * 3 + 2) * 8 + tidxj] = fiz[4 * h + k];
             }
-            __syncthreads();
+            wave_lds_sync();
             {
                 const float4 p0 = *reinterpret_cast<const float4 *>(&s_fj[lane * 8]);
                 const float4 p1 = *reinterpret_cast<const float4 *>(&s_fj[lane * 8 + 4]);
                 const float  o1 = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
+#ifdef NBX_DBG_NO_IATOMICS      // timing experiments only (wrong forces)
+                if (o1 == 1.2345e33f)
+#endif
                 atomicAdd(&fi[h * 96 + lane], o1);
                 s1 += o1;
             }
@@ -802,21 +1042,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
                 const float4 p0 = *reinterpret_cast<const float4 *>(&s_fj[(64 + lane) * 8]);
                 const float4 p1 = *reinterpret_cast<const float4 *>(&s_fj[(64 + lane) * 8 + 4]);
                 const float  o2 = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
+#ifdef NBX_DBG_NO_IATOMICS
+                if (o2 == 1.2345e33f)
+#endif
                 atomicAdd(&fi[h * 96 + 64 + lane], o2);
                 s2 += o2;
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 
+#if NBX_ZERO_AT_END
+    // in-kernel clear of the idle output buffer (nbnxn_hip_set_clear_in_kernel): the next step accumulates into it, so
+    // no fill has to be dispatched between two steps.  Issued last: loads, stores and atomics of a wave retire in order,
+    // so at the head of the kernel these stores stood in front of every load of the prologue.
+    for (int i = blockIdx.x * 64 + lane; i < p_zero_n4; i += gridDim.x * 64) { p_zero[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#endif
 #ifdef NBX_TIMELINE
     if (lane == 0 && blockIdx.x < 65536)
     {
         unsigned hwid;
         __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        nbx_timeline[3 * blockIdx.x]     = tl_t0;
-        nbx_timeline[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        nbx_timeline[3 * blockIdx.x + 2] = hwid | ((unsigned long long)(e.cj4_ind_end - e.cj4_ind_start) << 32);
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x]     = tl_t0;
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 1] = tl_t1;
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 2] = tl_t2;
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 4] = hwid | ((unsigned long long)(e.cj4_ind_end - e.cj4_ind_start) << 32);
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 5] = __builtin_amdgcn_s_memtime() - tl_c0;     // shader-clock cycles of the wave
     }
 #endif
     if (ENER)
@@ -845,12 +1097,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENER ? 
     }
 }
 
+// Up to how many atom types the per-entry LJ table in LDS is used (beyond: the global table through L1 / L2).  The
+// table costs ntype x 544 bytes of LDS per workgroup (1168 with the LJ-PME grid column) on top of 4.1 KB, and the
+// workgroups a CU holds follow from that; GMX_HIP_NB_LDS_TABLE_MAX_TYPES overrides (0: always the global table), for
+// the measurement of where the switch belongs (tools/lds_threshold_scan.py).
+inline int lds_table_max_types(int vmod)
+{
+    static const int env = getenv("GMX_HIP_NB_LDS_TABLE_MAX_TYPES") ? atoi(getenv("GMX_HIP_NB_LDS_TABLE_MAX_TYPES")) : -1;
+    if (env >= 0) { return env < MAX_LDS_TYPES ? env : MAX_LDS_TYPES; }
+    (void)vmod;
+    return MAX_LDS_TYPES;
+}
+
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
 void launch_flavour(const nbx_kernel_args_t &a, int nsci, hipStream_t stream)
 {
-    if (a.ntype <= MAX_LDS_TYPES)
+    if (a.ntype <= lds_table_max_types(VMOD))
     {
-        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, true>), dim3(nsci), dim3(64), (size_t)a.ntype * ljt_row_bytes(VMOD, ENER), stream,
+        // NBX_DBG_EXTRA_LDS: bytes of unused LDS per workgroup, to lower the occupancy in timing experiments
+        static const size_t extra_lds = getenv("NBX_DBG_EXTRA_LDS") ? (size_t)atoi(getenv("NBX_DBG_EXTRA_LDS")) : 0;
+        hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, true>), dim3(nsci), dim3(64), (size_t)a.ntype * ljt_row_bytes(VMOD, ENER) + extra_lds, stream,
                            NBX_KERNEL_CALL_ARGS(a));
     }
     else { hipLaunchKernelGGL((nbnxn_kernel<EL, ENER, PRUNE, VDWC, VMOD, false>), dim3(nsci), dim3(64), 0, stream, NBX_KERNEL_CALL_ARGS(a)); }

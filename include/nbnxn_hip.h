@@ -706,15 +706,16 @@ int nbnxn_hip_set_timing(nbnxn_hip_ptr_t nb, int on);
  *   - with NBX_FORCE_VIRIAL in flags, {e_lj, e_el, fshift[45][3]} (137 floats) are ASSIGNED to the caller's device
  *     array d_e_fshift; without it that array is not touched and may be NULL,
  * and the kernel's scratch buffer -- the 64 x 144-float partial-sum slots the waves add into, which every other
- * launch takes from the handle's allocation -- is a file-scope device array of the library: 36,864 bytes per GPU,
+ * launch takes from the handle's allocation -- is a file-scope device array of the library: 73,728 bytes per GPU (a half per locality),
  * held until the process ends, whatever the system size.  The call issues one fill of that array, the kernel and a
  * 137-thread fold kernel; it calls no hipMalloc / hipFree / allocating routine and returns without synchronising
  * (order later work after it on nbnxn_hip_get_stream(nb, iloc), or synchronise that stream).
  * Limits, refused with an error: natoms must equal the installed atom count and be <= NBX_NOALLOC_MAX_ATOMS, the
  * installed list may have at most NBX_NOALLOC_MAX_NSCI entries (32-bit indexing inside the kernels; the scratch
  * array itself does not grow with the system).  Every call on one GPU shares that GPU's array, which keeps the last
- * call's contents (the call clears it first): calls that overlap on one GPU -- two handles, or both localities of
- * one handle on different streams -- race on the energies; forces are unaffected.  A fresh list is pruned by this
+ * call's contents (the call clears its half first): the local and the non-local call of one two-stream handle may
+ * overlap (each locality has its own half of the array), calls of TWO handles that overlap on one GPU race on the
+ * energies; forces are unaffected.  A fresh list is pruned by this
  * launch as by any other (the handle's list masks are rewritten in place). */
 #define NBX_NOALLOC_MAX_ATOMS (1 << 28)
 #define NBX_NOALLOC_MAX_NSCI  (1 << 30)

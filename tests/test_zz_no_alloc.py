@@ -69,3 +69,47 @@ def test_no_alloc_entry_point_matches_the_existing_one_twice_in_a_row():
         _one_call(nb, torch, small, ip, abi.FORCE_VIRIAL)
     finally:
         nb.close()
+
+
+def test_no_alloc_local_and_nonlocal_back_to_back_on_a_two_stream_handle():
+    """Both localities of a two-stream handle, issued back to back so that they overlap on the device (each on its own
+    stream, each with its own half of the scratch array): energies and shift forces of the two calls together, and the
+    forces both add into ONE array, equal what the existing entry points give for the two lists (compute_both)."""
+    import torch
+    import torch.distributed as dist
+    from gromacs_cosmo_amd import dd
+    from test_dd_cpu import _free_port
+    nb = g.gpu.NbnxnHip(0, local_and_nonlocal=True)
+    made_group = not dist.is_initialized()
+    if made_group:      # build_domain gathers the halo bookkeeping through the process group, also for one rank
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        ip = g.system.ewald(0.9, rlist=1.0)
+        glob = g.system.water_box(2, 2, 4, model="spce")
+        dom = dd.build_domain(glob, ip, 0, 1, torch.device("cuda", 0), 300)      # one rank that is its own neighbour along z
+        nb.init_const(ip, dom.ntype, dom.nbfp)
+        nb.init_atomdata(dom.npad, dom.npad_local, dom.ntype, dom.type)
+        nb.upload_shiftvec(dom.shift_vec)
+        nb.init_pairlist(dom.pl_local, abi.LOCAL)
+        nb.init_pairlist(dom.pl_nonlocal, abi.NONLOCAL)
+        assert dom.pl_nonlocal.nsci > 0
+        fl = abi.FORCE_VIRIAL
+        f_ref, (elj, eel, fsh) = nb.compute_both(dom.xq, fl)              # existing entry points; prunes both lists
+        xq = torch.from_numpy(dom.xq).cuda()
+        for _ in range(2):
+            f = torch.zeros((dom.npad, 3), dtype=torch.float32, device="cuda")
+            e = torch.full((2, 137), 7.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            mem0 = torch.cuda.mem_get_info()[0]
+            nb.launch_kernel_noalloc(fl, dom.npad, xq.data_ptr(), f.data_ptr(), e[0].data_ptr(), iloc=abi.LOCAL)
+            nb.launch_kernel_noalloc(fl, dom.npad, xq.data_ptr(), f.data_ptr(), e[1].data_ptr(), iloc=abi.NONLOCAL)
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] == mem0
+            fh, eh = f.cpu().numpy(), e.cpu().numpy().astype(np.float64).sum(0)
+            assert np.isfinite(fh).all() and relrms(fh, f_ref) < 2e-6
+            assert abs(eh[0] - elj) <= 2e-6 * abs(elj) and abs(eh[1] - eel) <= 2e-6 * abs(eel)
+            assert np.abs(eh[2:].reshape(45, 3) - fsh).max() <= 2e-6 * np.abs(fsh).max()
+    finally:
+        nb.close()
+        if made_group:
+            dist.destroy_process_group()

@@ -27,7 +27,8 @@ for case in cases:
     el, fl = case.split("-")
     ip = g.system.ewald(1.0) if el == "ewald" else g.system.reaction_field(1.0)
     flags = abi.FORCE_VIRIAL if fl == "vf" else 0
-    s = g.system.water_box(5, 5, 6, model="spce" if el == "ewald" else "spc")
+    tiles = tuple(int(v) for v in os.environ.get("TILES", "5,5,6").split(","))
+    s = g.system.water_box(*tiles, model="spce" if el == "ewald" else "spc")
     p = g.workload.prepare(s, ip, hs[0].min_ci_balanced())
     for nb in hs:
         g.workload.upload(nb, p, ip)
@@ -39,10 +40,10 @@ for case in cases:
                 nb.clear_outputs(flags); nb.launch_kernel_resident(flags)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(200):
+            for _ in range(int(os.environ.get("AB_STEPS", "200"))):
                 nb.clear_outputs(flags); nb.launch_kernel_resident(flags)
             torch.cuda.synchronize()
-            res[k].append((time.perf_counter() - t0) / 200 * 1e6)
+            res[k].append((time.perf_counter() - t0) / int(os.environ.get("AB_STEPS", "200")) * 1e6)
     a, b = np.array(res[0][2:]), np.array(res[1][2:])
     print(f"{case}: A {os.path.basename(libs[0])} {np.median(a):.2f} us (min {a.min():.2f})   B {os.path.basename(libs[1])} {np.median(b):.2f} us (min {b.min():.2f})"
           f"   B/A {np.median(b) / np.median(a):.4f}", flush=True)

@@ -17,4 +17,12 @@ timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d $out/pmc_sq_ewald
 timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d $out/pmc_sq_rf -- $B $S --workload rf --force-only > $out/pmc_sq_rf.txt 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B $S > $out/pmc_fetch.txt 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B $S > $out/pmc_write.txt 2>&1 || exit 1
-for d in pmc_sq_ewald pmc_sq_rf pmc_fetch pmc_write; do echo $d; python3 $R/tools/pmc_summary.py $out/$d; done > $out/pmc_summary.txt
+# where a wave's cycles go, and the per-type VALU counters (hardware-counted FP32 operations): passes of their own
+WAVE="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
+FLOP="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_BRANCH"
+timeout -s KILL 120 rocprofv3 --pmc $WAVE --output-format csv -d $out/pmc_wave_ewald -- $B $S > $out/pmc_wave_ewald.txt 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc $WAVE --output-format csv -d $out/pmc_wave_rf -- $B $S --workload rf --force-only > $out/pmc_wave_rf.txt 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc $FLOP --output-format csv -d $out/pmc_flops_ewald -- $B $S > $out/pmc_flops_ewald.txt 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc $FLOP --output-format csv -d $out/pmc_flops_rf -- $B $S --workload rf --force-only > $out/pmc_flops_rf.txt 2>&1 || exit 1
+for d in pmc_sq_ewald pmc_sq_rf pmc_wave_ewald pmc_wave_rf pmc_flops_ewald pmc_flops_rf pmc_fetch pmc_write; do echo $d; python3 $R/tools/pmc_summary.py $out/$d; done > $out/pmc_summary.txt
+python3 $R/tools/pmc_flops.py $out $out/pmc_flops.json > /dev/null

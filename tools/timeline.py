@@ -1,6 +1,7 @@
 """Wave timeline of the force kernel (debug build: make -C gromacs-cosmo_amd/csrc timeline; run with
 NBNXN_HIP_LIB=gromacs-cosmo_amd/lib/dbg/libnbnxn_hip_tl.so).  Prints how many waves are resident over the launch,
-the ramp and the tail.  usage: NBNXN_HIP_LIB=... python tools/timeline.py [mcb]"""
+the ramp and the tail, and where a wave's time goes: before its first pair (prologue), in the pair loop, after it
+(i-force reduction, energies).  usage: NBNXN_HIP_LIB=... python tools/timeline.py [ewald-vf|ewald-f|rf-f|rf-vf] [mcb]"""
 import ctypes as C
 import os
 import sys
@@ -9,33 +10,75 @@ import numpy as np
 import gromacs_cosmo_amd as g
 from gromacs_cosmo_amd import abi
 
+case = sys.argv[1] if len(sys.argv) > 1 else "ewald-vf"
+el, fl = case.split("-")
 nb = g.gpu.NbnxnHip(0)
-mcb = int(sys.argv[1]) if len(sys.argv) > 1 else nb.min_ci_balanced()
-ip = g.system.ewald(1.0)
-s = g.system.water_box(5, 5, 6, model="spce")
+mcb = int(sys.argv[2]) if len(sys.argv) > 2 else nb.min_ci_balanced()
+ip = g.system.ewald(1.0) if el == "ewald" else g.system.reaction_field(1.0)
+s = g.system.water_box(5, 5, 6, model="spce" if el == "ewald" else "spc")
 p = g.workload.prepare(s, ip, mcb)
 g.workload.upload(nb, p, ip)
-flags = abi.FORCE_VIRIAL
-nb.compute(p.xq, flags)
+flags = abi.FORCE_VIRIAL if fl == "vf" else 0
+nb.compute(p.xq, abi.FORCE_VIRIAL)
+nb.set_timing(True)
 for _ in range(5):
     nb.clear_outputs(flags); nb.launch_kernel_resident(flags); nb.wait_gpu(flags)
 n = p.pl.nsci
-tl = np.zeros((n, 3), dtype=np.uint64)
-nb.lib.nbnxn_hip_debug_timeline.argtypes = [C.c_void_p, C.c_int]
-assert nb.lib.nbnxn_hip_debug_timeline(tl.ctypes.data_as(C.c_void_p), n) == 0
-t0 = tl[:, 0].astype(np.int64); t1 = tl[:, 1].astype(np.int64)
-ncj4 = (tl[:, 2] >> np.uint64(32)).astype(np.int64)
-base = t0.min()
-t0 = (t0 - base) * 0.01; t1 = (t1 - base) * 0.01      # us
-dur = t1 - t0
-print(f"nsci {n}  kernel span {t1.max():.1f} us (event timing {nb.last_kernel_ms() * 1e3:.1f} us)  sum of wave times {dur.sum():.0f} us"
-      f"  = {dur.sum() / t1.max():.0f} waves resident on average of 4096 slots")
+W = 6
+tl = np.zeros((n, W), dtype=np.uint64)
+fn = nb.lib.nbnxn_hip_debug_timeline if el == "ewald" else nb.lib.nbnxn_hip_debug_timeline_rf
+fn.argtypes = [C.c_void_p, C.c_int]
+assert fn(tl.ctypes.data_as(C.c_void_p), n) == 0
+t = tl[:, :4].astype(np.int64)
+ncj4 = (tl[:, 4] >> np.uint64(32)).astype(np.int64)
+hw = (tl[:, 4] & np.uint64(0xffffffff)).astype(np.int64)
+base = t[:, 0].min()
+t = (t - base) * 0.01      # us
+t0, t1, t2, t3 = t.T
+dur = t3 - t0
+span = t3.max()
+cyc = tl[:, 5].astype(np.float64)
+big = dur > 5.0
+print(f"shader clock while the kernel runs (cycles of a wave / its wall time, waves longer than 5 us): median {np.median(cyc[big] / dur[big]) / 1e3:.3f} GHz,"
+      f" 5th / 95th percentile {np.percentile(cyc[big] / dur[big], 5) / 1e3:.3f} / {np.percentile(cyc[big] / dur[big], 95) / 1e3:.3f}")
+slots = len(set(hw.tolist()))
+print(f"{case}: nsci {n}  kernel span {span:.1f} us (event timing {nb.last_kernel_ms() * 1e3:.1f} us)  sum of wave times {dur.sum():.0f} us"
+      f"  = {dur.sum() / span:.0f} waves resident on average; {slots} distinct hardware wave slots seen")
 print(f"wave duration us: min {dur.min():.2f} median {np.median(dur):.2f} max {dur.max():.2f};  per cj4 group median {np.median(dur / np.maximum(ncj4, 1)):.2f}")
-edges = np.linspace(0, t1.max(), 21)
+pro, loop, epi = t1 - t0, t2 - t1, t3 - t2
+print(f"share of all wave time: prologue {pro.sum() / dur.sum():.3f}  pair loop {loop.sum() / dur.sum():.3f}  epilogue {epi.sum() / dur.sum():.3f}")
+print(f"per entry, median us: prologue {np.median(pro):.2f}  pair loop {np.median(loop):.2f}  epilogue {np.median(epi):.2f};"
+      f"  pair loop per cj4 group: median {np.median(loop / np.maximum(ncj4, 1)):.2f} us")
+q = np.argsort(t0)
+for name, sel in (("first 25% of entries", q[: n // 4]), ("middle 50%", q[n // 4: 3 * n // 4]), ("last 25%", q[3 * n // 4:])):
+    print(f"  {name}: groups per entry {ncj4[sel].mean():.1f}, prologue {pro[sel].mean():.2f}  loop per group {(loop[sel] / np.maximum(ncj4[sel], 1)).mean():.2f}"
+          f"  epilogue {epi[sel].mean():.2f} us")
+edges = np.linspace(0, span, 21)
 for a, b in zip(edges[:-1], edges[1:]):
     mid = 0.5 * (a + b)
-    res = int(((t0 <= mid) & (t1 > mid)).sum())
-    print(f"  t = {mid:6.1f} us: {res:5d} waves resident, {int(((t0 >= a) & (t0 < b)).sum()):5d} started")
-last = np.sort(t1)[::-1]
-print("last waves end at", np.round(last[:5], 1), " 99%/95%/90% of waves ended by", np.round(np.percentile(t1, [99, 95, 90]), 1))
+    res = int(((t0 <= mid) & (t3 > mid)).sum())
+    inloop = int(((t1 <= mid) & (t2 > mid)).sum())
+    print(f"  t = {mid:6.1f} us: {res:5d} waves resident ({inloop:5d} in the pair loop), {int(((t0 >= a) & (t0 < b)).sum()):5d} started")
+last = np.sort(t3)[::-1]
+print("last waves end at", np.round(last[:5], 1), " 99%/95%/90% of waves ended by", np.round(np.percentile(t3, [99, 95, 90]), 1))
 print("first wave of the final 10% starts at", np.round(np.sort(t0)[int(0.9 * n)], 1))
+
+# where the time per unit of work goes over the launch: entries binned by their start time; work = live cluster pairs
+# (set bits of the pruned interaction masks) and j-clusters with at least one live pair
+pl = nb.download_pairlist()
+im = (pl.cj4["imei"]["imask"][:, 0] | pl.cj4["imei"]["imask"][:, 1]).astype(np.uint32)
+live = np.array([bin(int(v)).count("1") for v in im], dtype=np.int64)
+jlive = np.array([sum(1 for k in range(4) if (int(v) >> (8 * k)) & 0xff) for v in im], dtype=np.int64)
+cs_live, cs_j = np.concatenate([[0], np.cumsum(live)]), np.concatenate([[0], np.cumsum(jlive)])
+a0, a1 = pl.sci["cj4_ind_start"].astype(np.int64), pl.sci["cj4_ind_end"].astype(np.int64)
+e_live, e_j = cs_live[a1] - cs_live[a0], cs_j[a1] - cs_j[a0]
+print(f"live cluster pairs {live.sum()}, per group {live.mean():.2f}, per live j-cluster {live.sum() / max(jlive.sum(), 1):.2f}")
+print("entries by start time:   n  groups/entry  live pairs/group   loop us/group  loop ns/live pair   prologue  epilogue")
+edges = np.percentile(t0, [0, 10, 25, 40, 55, 70, 85, 100])
+edges[-1] += 1
+for lo, hi in zip(edges[:-1], edges[1:]):
+    m = (t0 >= lo) & (t0 < hi)
+    if m.sum() == 0:
+        continue
+    print(f"  start {lo:5.1f}-{hi:5.1f} us: {int(m.sum()):5d}  {ncj4[m].mean():6.1f}  {e_live[m].sum() / max(ncj4[m].sum(), 1):8.2f}"
+          f"  {loop[m].sum() / max(ncj4[m].sum(), 1):10.2f}  {1e3 * loop[m].sum() / max(e_live[m].sum(), 1):10.1f}    {pro[m].mean():6.2f}  {epi[m].mean():6.2f}")
