@@ -82,6 +82,94 @@ def large_system_leg(g, abi, ip, flags, model, flops_pair, peak_tflops, tiles=(1
             "note": "wall time per step (not kernel events), same flavour and flop count as the headline workload"}
 
 
+def counted_flops(workload, ener):
+    """Hardware-counted FP32 operations per launch of the timed kernel (rocprofv3 --pmc with the per-type VALU counters,
+    tools/profile_round.sh -> tools/pmc_flops.py): quoted only while nbnxn_kernel.hip is byte for byte the source the
+    counters were taken on (its SHA-256 is stored with them) and the workload is one of the two that were profiled."""
+    import glob
+    import hashlib
+    key = {("ewald", True): "ewald_vf", ("rf", False): "rf_f"}.get((workload, ener))
+    if key is None:
+        return None
+    sha = hashlib.sha256(open(os.path.join(ROOT, "gromacs-cosmo_amd", "csrc", "nbnxn_kernel.hip"), "rb").read()).hexdigest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_flops.json")), reverse=True):
+        d = json.load(open(path))
+        if d.get("kernel_source_sha256") == sha and key in d:
+            return dict(d[key], file=os.path.basename(path), counting_rule=d["counting_rule"])
+    return None
+
+
+def mixture_leg(g, abi, peak_tflops, sizes=(100000, 3000000)):
+    """Secondary figure, outside the timed region of `value`: BASELINE configs[4] in kind -- the 8-type chain mixture with
+    15-30 exclusions per atom (system.lj_chain_mixture; 9 types in the table with the filler type), analytical Ewald,
+    energies + virial every step, at ~100 k and 3 M atoms on this one GPU, and once with LJ-PME.  The per-entry LJ table
+    in LDS grows with the number of types (544 B per type, 1168 B with the LJ-PME grid column), so this is where its
+    cost in resident workgroups would show."""
+    import torch
+    out = {}
+    nb = g.gpu.NbnxnHip(0)
+    nb.set_timing(False)
+    nb.set_clear_in_kernel(True)
+    fl = abi.FORCE_VIRIAL
+    for natoms in sizes:
+        s = g.system.lj_chain_mixture(natoms)
+        for name, ip in (("ewald", g.system.ewald(1.0)),) + ((("ewald_ljpme", g.system.with_ljpme(g.system.ewald(1.0), abi.LJCR_GEOM)),) if natoms <= 200000 else ()):
+            p = g.workload.prepare(s, ip, nb.min_ci_balanced())
+            g.workload.upload(nb, p, ip)
+            nb.compute(p.xq, fl)                      # prune step, coordinates resident
+            n = 200 if natoms <= 200000 else 30
+            for _ in range(10):
+                nb.clear_outputs(fl); nb.launch_kernel_resident(fl)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                nb.clear_outputs(fl); nb.launch_kernel_resident(fl)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / n
+            lds = 4100 + p.ntype * (1168 if name.endswith("ljpme") else 544)
+            out[f"{name}_{natoms}"] = {"atoms": s.natoms, "ntype": int(p.ntype), "pair_slots_per_step": p.pair_slots, "nsci": p.pl.nsci, "nexcl": p.pl.nexcl,
+                                       "ms_per_step": ms, "pairs_per_s": p.pair_slots / (ms * 1e-3),
+                                       "roofline_frac": p.pair_slots * FLOPS[("ewald", True)] / (ms * 1e-3) / 1e12 / peak_tflops,
+                                       "lds_bytes_per_workgroup": lds}
+    nb.close()
+    out["note"] = ("wall time per step of back-to-back launches; roofline_frac by nrnb's 107 flops per pair slot as for the headline (LJ-PME costs more "
+                   "than that per pair, so its fraction understates it); 9 atom types: the LDS table is in use (tools/lds_threshold_scan.py for where it stops paying)")
+    return out
+
+
+def strong_leg(g, abi, dd, dist, torch, ip, flags, model, rank, world, local_rank, rccl_direct, flops_pair, tiles=(13, 13, 14), nsteps=60):
+    """Secondary figure of an N > 1 run, outside the timed region of `value`: BASELINE configs[3], ONE 1,533,168-atom box cut
+    into `world` z slabs (strong scaling), so that one driver command gives the weak-scaling line and this point."""
+    run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=True)
+    run.nb.set_timing(False)
+    for _ in range(10):
+        run.step()
+    run.flush()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        run.step()
+    run.flush()
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall, float(run.pair_slots_local)], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+    tmax, tsum = t.clone(), t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    d = run.describe()
+    natoms = run.natoms_global
+    torch.cuda.synchronize()
+    dist.barrier()
+    run.nb.close()
+    ms = 1e3 * float(tmax[0]) / nsteps
+    return {"atoms": natoms, "scaling": "strong", "n_gpus": world, "ms_per_step": ms, "pairs_per_s": float(tsum[1]) / (ms * 1e-3),
+            "ns_per_day": 86400.0 * DT_FS * 1e-6 / (ms * 1e-3), "roofline_frac_of_n_gpus": float(tsum[1]) * flops_pair / (ms * 1e-3) / 1e12 / (FP32_VECTOR_PEAK_TFLOPS * world),
+            "halo_route": d["halo_route"], "rccl_ranks": d["rccl_ranks"], "halo_atoms_rank0": d["halo_atoms_rank0"], "steps": nsteps,
+            "note": "python bench.py --gpus N --tiles 13,13,14 --strong gives the same as a headline line"}
+
+
 def decomposed_step_leg(timeout_s=150):
     """Secondary figure, outside the timed region of `value`: the domain-decomposed step (what --gpus N runs on every
     rank) on ONE rank that is its own neighbour, so that the halo messages are real RCCL sends / receives on this one
@@ -405,7 +493,14 @@ def main():
         run = dd.SlabRun(tiles, model, ip, rank, world, local_rank, flags, rccl_direct=rccl_direct, strong=args.strong, grid=grid,
                          self_dims=self_dims, scheme=args.dd_scheme, balance=args.dd_balance,
                          film=(lambda v: (float(v[0]), int(v[1])))(args.dd_film.split(",")) if args.dd_film else None)
-        rccl_direct = run.rccl_direct   # False on every rank when one of them cannot reach RCCL from the module
+        if rccl_direct and not run.rccl_direct:
+            # the module's own RCCL path was asked for and every rank fell back to torch.distributed: that is not the
+            # configuration this line is supposed to measure (BENCH_DD_TORCH=1 asks for the torch route on purpose)
+            print(f"[bench rank {rank}] the module's RCCL path is not in use (see the ranks' messages above): refusing to report "
+                  "a number for another route; BENCH_DD_TORCH=1 measures the torch.distributed route", file=sys.stderr, flush=True)
+            run.nb.close()
+            dist.destroy_process_group()
+            raise SystemExit(3)
         run.nb.set_timing(False)     # as for one GPU: the bench times the local kernel with its own events
         natoms = run.natoms_global
         pair_slots = run.pair_slots_local    # summed over ranks below
@@ -520,6 +615,15 @@ def main():
                          "kernel_ms": kernel_ms, "kernel_ms_events_raw": kernel_ms_raw, "event_pair_ms": event_pair_ms,
                          "note": "algorithmic flops = pair slots x nrnb.c cost (gmxlib/nrnb.c:101-106); duration = mean HIP-event time around the nonbonded kernel launch inside the timed region minus the latency of an empty event pair"},
         }
+        cf = counted_flops(args.workload, ener) if not decomposed and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split else None
+        if cf:
+            out["roofline"]["achieved_counted"] = cf["flop_per_launch"] / (kernel_ms * 1e-3) / 1e12
+            out["roofline"]["frac_counted"] = out["roofline"]["achieved_counted"] / FP32_VECTOR_PEAK_TFLOPS
+            out["roofline"]["counted"] = {"flop_per_launch": cf["flop_per_launch"], "counters_per_launch": cf["counters_per_launch"],
+                                          "lanes_on_share": cf["lanes_on_share"], "rule": cf["counting_rule"], "file": "profiles/" + cf["file"]}
+        if decomposed:
+            out["halo_route"] = cfg_extra.get("halo_route")
+            out["rccl_ranks"] = cfg_extra.get("rccl_ranks")
         if not args.no_cpu and not decomposed and natoms > 400000:
             # a box of BASELINE configs[3] size: the CPU leg alone (bounded); the full-list oracle pass and the
             # secondary figures belong to the default workload
@@ -538,12 +642,26 @@ def main():
             out["verlet_loop"] = verlet_loop_leg(g, abi, system, ip, flags)
             out["large_system"] = large_system_leg(g, abi, ip, flags, model, flops_pair, FP32_VECTOR_PEAK_TFLOPS)
             out["decomposed_step_one_rank"] = decomposed_step_leg()
-        print(json.dumps(out), flush=True)
+            if args.workload == "ewald" and ener and tiles == (5, 5, 6):
+                out["large_mixture"] = mixture_leg(g, abi, FP32_VECTOR_PEAK_TFLOPS)
+    strong = None
     if decomposed:
         sync()
         dist.barrier()
         run.nb.close()               # also destroys the module's RCCL communicator, on every rank
+        if world > 1 and not args.strong and not args.dd_self and not args.dd_grid and not args.dd_film and tiles == (5, 5, 6) \
+                and os.environ.get("BENCH_NO_STRONG_LEG") != "1":
+            progress("secondary leg: BASELINE configs[3], one box cut into slabs (strong scaling)")
+            try:
+                strong = strong_leg(g, abi, dd, dist, torch, ip, flags, model, rank, world, local_rank, rccl_direct, flops_pair,
+                                    tiles=(13, 13, 14) if not rehearsal else (2, 2, 4))
+            except (RuntimeError, AssertionError, MemoryError) as err:
+                strong = {"error": repr(err)[:300]}
         dist.destroy_process_group()
+    if rank == 0:
+        if strong is not None:
+            out["strong_1p5M"] = strong
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

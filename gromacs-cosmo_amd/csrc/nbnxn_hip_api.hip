@@ -1797,6 +1797,7 @@ struct RcclApi {
     decltype(&ncclSend)           Send           = nullptr;
     decltype(&ncclRecv)           Recv           = nullptr;
     decltype(&ncclAllReduce)      AllReduce      = nullptr;
+    decltype(&ncclCommCount)      CommCount      = nullptr;
     bool                          bound          = false;
 };
 RcclApi g_rccl;
@@ -1813,7 +1814,7 @@ int dd_bind()
     g_rccl.name = reinterpret_cast<decltype(g_rccl.name)>(dlsym(h, "nccl" #name));      \
     if (!g_rccl.name) { return nbx_fail("RCCL lacks nccl" #name); }
     NBX_BIND(GetUniqueId) NBX_BIND(CommInitRank) NBX_BIND(CommDestroy) NBX_BIND(GetErrorString)
-    NBX_BIND(GroupStart) NBX_BIND(GroupEnd) NBX_BIND(Send) NBX_BIND(Recv) NBX_BIND(AllReduce)
+    NBX_BIND(GroupStart) NBX_BIND(GroupEnd) NBX_BIND(Send) NBX_BIND(Recv) NBX_BIND(AllReduce) NBX_BIND(CommCount)
 #undef NBX_BIND
     g_rccl.bound = true;
     return 0;
@@ -1858,6 +1859,14 @@ int nbnxn_hip_dd_init(nbnxn_hip_ptr_t nb, const char *id128, int rank, int nrank
     memcpy(&id, id128, sizeof(id));
     RCCL_TRY(g_rccl.CommInitRank(&nb->dd_comm, nranks, id, rank));
     nb->dd_rank = rank; nb->dd_nranks = nranks;
+    return 0;
+}
+
+int nbnxn_hip_dd_comm_count(nbnxn_hip_ptr_t nb, int *nranks)
+{
+    if (check_dd(nb)) { return 1; }
+    if (!nranks) { return nbx_fail("null result pointer"); }
+    RCCL_TRY(g_rccl.CommCount(nb->dd_comm, nranks));
     return 0;
 }
 

@@ -98,9 +98,18 @@ inline float bb_dist2(const BB &a, const BB &b)
 
 // Sort `idx[0..n)` by coordinate dim ascending; ties by atom index so that the order does
 // not depend on the input order (the reference sorts for "binary reproducibility",
-// nbnxn_search.c:679-687).
-void sort_dim(int *idx, int n, const float *x, int a0, int dim)
+// nbnxn_search.c:679-687).  backwards: the reference's sort_atoms(..., Backwards = TRUE), which reads its
+// sorted slots from the top down (:724-734): coordinate descending, ties by DEScending atom index.
+void sort_dim(int *idx, int n, const float *x, int a0, int dim, bool backwards = false)
 {
+    if (backwards)
+    {
+        std::sort(idx, idx + n, [&](int p, int q) {
+            float xp = x[3 * (p - a0) + dim], xq = x[3 * (q - a0) + dim];
+            return xp > xq || (xp == xq && p > q);
+        });
+        return;
+    }
     std::sort(idx, idx + n, [&](int p, int q) {
         float xp = x[3 * (p - a0) + dim], xq = x[3 * (q - a0) + dim];
         return xp < xq || (xp == xq && p < q);
@@ -259,13 +268,16 @@ int nbnxn_host_put_on_grid(nbnxn_host_ptr_t h, int zone,
                 g.bbcz[2 * sc + 1] = x[3 * (col_a[ash_z + na_c - 1] - a0) + 2];
             }
             if (na_z <= 0) { continue; }
-            sort_dim(col_a + ash_z, na_z, x, a0, 1);
+            // y within a z-half, x within a y-half: every other sub-cell is sorted BACKWARDS, so that consecutive
+            // sub-cells snake through the super-cell (sort_columns_supersub, nbnxn_search.c:1448 and :1462:
+            // Backwards = sub_z & 1 for y, (cz * GPU_NSUBCELL_Y + sub_y) & 1 = sub_y & 1 for x)
+            sort_dim(col_a + ash_z, na_z, x, a0, 1, (sub_z & 1) != 0);
             for (int sub_y = 0; sub_y < 2; sub_y++)
             {
                 const int ash_y = ash_z + sub_y * 16;
                 const int na_y  = std::min(16, na - ash_y);
                 if (na_y <= 0) { continue; }
-                sort_dim(col_a + ash_y, na_y, x, a0, 0);
+                sort_dim(col_a + ash_y, na_y, x, a0, 0, (sub_y & 1) != 0);
                 for (int sub_x = 0; sub_x < 2; sub_x++)
                 {
                     const int ash_x = ash_y + sub_x * NA_C;

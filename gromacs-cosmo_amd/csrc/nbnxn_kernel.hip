@@ -1105,8 +1105,12 @@ inline int lds_table_max_types(int vmod)
 {
     static const int env = getenv("GMX_HIP_NB_LDS_TABLE_MAX_TYPES") ? atoi(getenv("GMX_HIP_NB_LDS_TABLE_MAX_TYPES")) : -1;
     if (env >= 0) { return env < MAX_LDS_TYPES ? env : MAX_LDS_TYPES; }
-    (void)vmod;
-    return MAX_LDS_TYPES;
+    // Measured on the 100 k-atom chain mixture, Ewald V+F, LDS table / global table (profiles/r3_b_lds_threshold.txt):
+    // cut-off LJ (8-byte entries) 0.87-0.92 for 3 ... 16 types: the LDS table always pays, although from 11 types on
+    // it costs resident workgroups (16 -> 11 per CU).  LJ-PME (16-byte entries, 1168 B per type): 0.94 at 3 and 5
+    // types, 1.07 at 7, 1.11 at 9, 1.17 at 15: beyond 6 types the table takes the CU below 16 workgroups and the
+    // global table wins.
+    return vmod == 3 ? 6 : MAX_LDS_TYPES;
 }
 
 template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>

@@ -287,13 +287,21 @@ k_supercells(int cell0, int nc, int ncxy, GridDims g, const int *__restrict__ cx
     const float z_first   = __shfl(pz_sorted, 0);
     const float z_last    = __shfl(pz_sorted, na_c - 1);
 
+    // y within each z-half, then x within each y-half; every other sub-cell BACKWARDS, as the reference's
+    // sort_atoms(..., Backwards) gives it (nbnxn_search.c:1448: sub_z & 1 for y; :1462: (cz * 2 + sub_y) & 1 = sub_y & 1
+    // for x; :724-734: coordinate descending, ties by descending atom index, unused slots still last).  A backward
+    // group sorts the negated coordinate and the mirrored index ascending.
     SortItem v;
-    v.idx = at >= 0 ? at : INT_MAX;
-    v.key = at >= 0 ? x[3 * at + 1] : INFINITY;
+    const bool back_y = ((lane >> 5) & 1) != 0;
+    v.idx = at >= 0 ? (back_y ? INT_MAX - 1 - at : at) : INT_MAX;
+    v.key = at >= 0 ? (back_y ? -x[3 * at + 1] : x[3 * at + 1]) : INFINITY;
     group_sort<32>(v, lane);
-    v.key = v.idx != INT_MAX ? x[3 * v.idx + 0] : INFINITY;
+    at = v.idx != INT_MAX ? (back_y ? INT_MAX - 1 - v.idx : v.idx) : -1;
+    const bool back_x = ((lane >> 4) & 1) != 0;
+    v.idx = at >= 0 ? (back_x ? INT_MAX - 1 - at : at) : INT_MAX;
+    v.key = at >= 0 ? (back_x ? -x[3 * at + 0] : x[3 * at + 0]) : INFINITY;
     group_sort<16>(v, lane);
-    at = v.idx != INT_MAX ? v.idx : -1;
+    at = v.idx != INT_MAX ? (back_x ? INT_MAX - 1 - v.idx : v.idx) : -1;
 
     float px = 0, py = 0, pz = 0;
     if (at >= 0) { px = x[3 * at]; py = x[3 * at + 1]; pz = x[3 * at + 2]; }

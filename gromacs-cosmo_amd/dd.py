@@ -809,7 +809,13 @@ class SlabRun:
             # The module's communicator and its first exchange, checked: the exchange must bring exactly the coordinates
             # the set-up brought through torch.distributed.  A rank whose RCCL call returns an error, or whose halo comes
             # out different, takes every rank back to torch.distributed (the ranks agree first).
+            # What the fall-back can and cannot recover from: an error RETURNED by a call (library not found, a refused
+            # argument) and a wrong halo are local facts a rank can report, and the ranks then agree.  A peer that never
+            # posts its side of the exchange is not: RCCL's kernel then never ends, nothing on this stream can follow,
+            # and pretending to fall back would only move the hang.  So the wait for the first exchange has a deadline,
+            # and a rank that runs into it ends the run with an error.
             ok = 1
+            want = slots = None
             try:
                 self.halo = RcclHalo(nb, dom, self.dev)
                 slots = self.halo.halo_slots
@@ -817,15 +823,26 @@ class SlabRun:
                 self.xq_t[slots, :3] = 1e6
                 torch.cuda.synchronize(self.dev)          # torch's stream wrote; the module's non-local stream exchanges
                 self.halo.send_x()
+                done = torch.cuda.Event()
+                done.record(torch.cuda.ExternalStream(nb.stream(abi.NONLOCAL), device=self.dev))
+                t_end = _time.perf_counter() + float(os.environ.get("NBNXN_DD_FIRST_EXCHANGE_TIMEOUT_S", "60"))
+                while not done.query():
+                    if _time.perf_counter() > t_end:
+                        raise SystemExit(f"rank {rank}: the module's first halo exchange over RCCL did not complete (a peer never posted "
+                                         "its side, or RCCL cannot reach it): no fall-back is possible from here")
+                    _time.sleep(0.001)
                 torch.cuda.synchronize(self.dev)
                 if not torch.equal(self.xq_t[slots], want):
                     ok = 0
-                    self.xq_t[slots] = want
                     print(f"rank {rank}: the module's first halo exchange over RCCL brought other coordinates than the set-up; "
                           "using torch.distributed", file=sys.stderr, flush=True)
             except gpu.HipError as err:
                 ok = 0
                 print(f"rank {rank}: the module's RCCL exchange failed ({err}); using torch.distributed", file=sys.stderr, flush=True)
+            if not ok and want is not None:
+                torch.cuda.synchronize(self.dev)
+                self.xq_t[slots] = want                   # whatever went wrong after the halo rows were wrecked: put them back
+                torch.cuda.synchronize(self.dev)
             t = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend() != "gloo" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if not int(t.item()):
@@ -858,7 +875,9 @@ class SlabRun:
 
     def describe(self):
         d = self.dom
-        return {"dd_grid": list(d.grid), "halo_messages": len(d.msgs), "halo_zones": len(d.zones) - 1,
+        route = {"halo_route": "module-rccl" if self.rccl_direct else ("torch+module-kernels" if self.device_halo else "torch"),
+                 "rccl_ranks": self.nb.dd_comm_count() if self.rccl_direct else None}
+        return {**route, "dd_grid": list(d.grid), "halo_messages": len(d.msgs), "halo_zones": len(d.zones) - 1,
                 "atoms_rank0": d.nhome, "halo_atoms_rank0": d.nhalo, "nsci_local": d.pl_local.nsci,
                 "nsci_nonlocal": d.pl_nonlocal.nsci, "cluster_pairs_rank0": d.pl_local.nci_tot + d.pl_nonlocal.nci_tot,
                 **({"load_imbalance_per_balancing_step": [round(v, 3) for v in d.balance_history]} if d.balance_history else {})}

@@ -121,6 +121,7 @@ def load():
     lib.nbnxn_hip_reserved_cus.argtypes = [vp]
     lib.nbnxn_hip_dd_get_unique_id.argtypes = [C.c_char_p]
     lib.nbnxn_hip_dd_init.argtypes = [vp, C.c_char_p, ci, ci]
+    lib.nbnxn_hip_dd_comm_count.argtypes = [vp, C.POINTER(C.c_int)]
     lib.nbnxn_hip_dd_set_pulse.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci]
     lib.nbnxn_hip_dd_set_messages.argtypes = [vp, ci, vp, vp, vp]
     lib.nbnxn_hip_dd_set_phases.argtypes = [vp, ci, vp]
@@ -424,6 +425,12 @@ class NbnxnHip:
     def dd_init(self, unique_id, rank, nranks):
         assert len(unique_id) == abi.DD_UNIQUE_ID_BYTES
         self._chk(self.lib.nbnxn_hip_dd_init(self.h, unique_id, rank, nranks))
+
+    def dd_comm_count(self):
+        """ranks of the module's RCCL communicator, from ncclCommCount"""
+        n = C.c_int(0)
+        self._chk(self.lib.nbnxn_hip_dd_comm_count(self.h, C.byref(n)))
+        return n.value
 
     def dd_set_pulse(self, send_to, recv_from, send_slots, recv_slots, shift=None, shift_index=-1):
         ss = np.ascontiguousarray(send_slots, dtype=np.int32)

@@ -617,6 +617,10 @@ int nbnxn_hip_reserved_cus(nbnxn_hip_ptr_t nb);
 int nbnxn_hip_dd_get_unique_id(char *id128);
 /* ncclCommInitRank on the handle's device: collective over the nranks ranks of the id */
 int nbnxn_hip_dd_init(nbnxn_hip_ptr_t nb, const char *id128, int rank, int nranks);
+/* how many ranks the module's communicator holds, as RCCL itself reports it (ncclCommCount): what a benchmark line
+ * quotes to show that the halo messages went between that many devices.  No counterpart in the reference (its halo is
+ * host MPI, domdec.c:651-875). */
+int nbnxn_hip_dd_comm_count(nbnxn_hip_ptr_t nb, int *nranks);
 /* Per search: coordinates of the grid slots send_slots go to rank send_to (plus shift, the box
  * vector of a pulse across a periodic boundary, NULL = none), coordinates for the slots recv_slots
  * arrive from rank recv_from; forces travel the reverse way, and those that arrive add to the shift

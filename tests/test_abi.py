@@ -82,3 +82,56 @@ def test_reference_side_binding_compiles_and_links():
                  "init_gpu", "free_gpu", "get_current_gpu_device_id", "get_gpu_device_id", "get_gpu_device_info_string",
                  "sizeof_cuda_dev_info", "do_quick_memtest", "do_full_memtest", "do_timed_memtest"):
         assert re.search(r"\b" + name + r"\(", text), name
+
+
+def test_dd_binding_translates_the_reference_pulses():
+    """include/nbnxn_hip_dd_gmx.h turns the pulses of the reference's decomposition (gmx_domdec_t plus the fields of the
+    private gmx_domdec_ind_t, domdec.c:100-123) into nbx_dd_message_t + phases.  Where the reference tree exists the unit is
+    compiled against the reference's own types (oracle/binding_check_dd.c, pointer mismatches are errors) and linked against
+    libnbnxn_hip.so; its host-only run translates a hand-made decomposition -- two dimensions, the second with two pulses
+    that are not in place, forwarding, periodic boundaries in a triclinic box -- and what it prints is compared with what
+    dd_move_x / dd_move_f do with the same pulses (domdec.c:651-875), worked out here."""
+    import subprocess
+    ref = "/root/reference/src/gromacs/legacyheaders/types/commrec.h"
+    exe = os.path.join(ROOT, "oracle", "_ref", "binding_check_dd")
+    if os.path.exists(ref):
+        r = subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle"), "_ref/binding_check_dd"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "warning" not in (r.stdout + r.stderr)
+    elif not os.path.exists(exe):
+        pytest.skip("oracle/_ref not built (no reference tree here)")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+
+    # the decomposition of binding_check_dd.c::self_test
+    cgindex = [0, 3, 6, 9, 12, 15, 18]
+    a = [2, 0, 1, 5, 4, 3, -1, -1, 8, 7, 6, 11, 9, 10, -1, 14, 13, 12, 17, 16, 15, -1, -1, -1]
+    box = [[4.0, 0.0, 0.0], [0.5, 3.0, 0.0], [0.0, 0.0, 2.0]]
+    neighbor = [[1, 3], [2, 5]]
+    dim = [0, 1]
+    pulses = [dict(d=0, index=[1], recv=list(range(6, 9))),                       # in place: appended behind the home atoms
+              dict(d=1, index=[0, 2], recv=list(range(9, 12)) + list(range(15, 18))),   # cell2at ranges of zones 2 and 3
+              dict(d=1, index=[3], recv=list(range(12, 15)))]
+    cell = {at: s for s, at in enumerate(a) if at >= 0}
+    send, recv = [], []
+    for k, p in enumerate(pulses):
+        atoms = [j for cg in p["index"] for j in range(cgindex[cg], cgindex[cg + 1])]
+        send += [cell[j] for j in atoms]
+        recv += [cell[j] for j in p["recv"]]
+        vis = [0, 0, 0]
+        vis[dim[p["d"]]] = 1
+        shift_index = 5 * (3 * (vis[2] + 1) + vis[1] + 1) + vis[0] + 2            # XYZ2IS, types/ishift.h:45-56
+        sh = box[dim[p["d"]]]
+        want = (f"msg {k} to {neighbor[p['d']][1]} from {neighbor[p['d']][0]} n_send {len(atoms)} n_recv {len(p['recv'])} "
+                f"shift_index {shift_index} shift {sh[0]:g} {sh[1]:g} {sh[2]:g} phase_end {k + 1}")
+        assert lines[k] == want
+    assert lines[3] == "send " + " ".join(str(v) for v in send)
+    assert lines[4] == "recv " + " ".join(str(v) for v in recv)
+    assert lines[5] == "no fshift: rc 0 shift_index -1 -1 -1"
+    assert lines[6] == "inner in y: rc 0 shift_index 23 -1 -1 shift_y 0 0 0"
+    assert all(l.startswith("refused -1: ") for l in lines[7:11]) and len(lines) == 11
+    # the accessor that reads the private structs is part of the header, for domdec.c to include
+    text = open(os.path.join(ROOT, "include", "nbnxn_hip_dd_gmx.h")).read()
+    for name in ("nbnxn_hip_dd_gmx_translate", "nbnxn_hip_dd_gmx_bind", "dd_get_nbnxn_hip_pulses", "NBNXN_HIP_DD_GMX_IN_DOMDEC"):
+        assert name in text

@@ -28,7 +28,7 @@ DEADLINE_S = 100
 
 
 def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_direct=False, grid=None, self_dims=(2,), scheme="half",
-            balance=0, film=None):
+            balance=0, film=None, break_rccl=False):
     import datetime
     import faulthandler
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -44,12 +44,25 @@ def _worker(rank, world, port, model, device_halo, ret, backend="gloo", rccl_dir
     try:
         ip = g.system.reaction_field(0.9, rlist=1.0) if model == "spc" else g.system.ewald(0.9, rlist=1.0)
         tiles = (2, 2, 2)
+        if break_rccl:
+            # the module's first exchange brings one wrong row: SlabRun's self-check has to notice, put the rows back
+            # and take the run to torch.distributed
+            real_send_x = dd.RcclHalo.send_x
+
+            def bad_send_x(self):
+                real_send_x(self)
+                d_xq, _, _ = self.nb.device_buffers()
+                xq = torch.as_tensor(dd._DevArray(d_xq, (self.dom.npad, 4)), device=torch.device("cuda", 0))
+                torch.cuda.synchronize()
+                xq[int(self.halo_slots[0]), 0] += 0.25
+                torch.cuda.synchronize()
+            dd.RcclHalo.send_x = bad_send_x
         run = dd.SlabRun(tiles, model, ip, rank, world, 0, abi.FORCE_VIRIAL, min_ci_balanced=300, device_halo=device_halo,
                          rccl_direct=rccl_direct, grid=grid, self_dims=self_dims, scheme=scheme, balance=balance, film=film)
         dom = run.dom
         # a test that asks for the module's own RCCL path must get it: the fall-back to torch.distributed is for
         # production runs, here it would hide a broken nbnxn_hip_dd_* path behind a line on stderr
-        assert run.rccl_direct == rccl_direct, "the module's RCCL path fell back to torch.distributed"
+        assert run.rccl_direct == (rccl_direct and not break_rccl), "the module's RCCL path fell back to torch.distributed"
         assert len(dom.msgs) == {"half": {1: 1, 2: 4, 3: 13}, "eighth": {1: 1, 2: 3, 3: 7}, "staged": {1: 1, 2: 2, 3: 3}}[scheme][sum(dom.decomp)]
         # wreck the imported coordinates on the device: the step has to bring them back
         run.xq_t[run.halo.halo_slots, :3] = 1e6
@@ -136,6 +149,21 @@ def test_slabrun_one_rank_over_rccl(model, rccl_direct, reserve_cus, monkeypatch
     with mp.Manager() as m:
         ret = m.dict()
         _watch(mp.spawn(_worker, args=(1, _free_port(), model, True, ret, "nccl", rccl_direct), nprocs=1, join=False))
+        r = ret[0]
+    assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
+    assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r
+    assert abs(r["e_el"] - r["e_el_ref"]) < 1e-5 * abs(r["e_el_ref"]), r
+    assert r["vir_err"] < 1e-5, r
+
+
+def test_fall_back_from_a_broken_rccl_exchange():
+    """The module's first exchange over RCCL brings one wrong coordinate (a patched RcclHalo.send_x): SlabRun's check
+    against the coordinates the set-up brought has to catch it, restore the halo rows it had wrecked for the check and
+    carry on through torch.distributed -- forces, energies and virial still those of the single domain.  (The tests
+    that ask for the module's path assert that they GOT it, so a fall-back cannot hide a broken path there.)"""
+    with mp.Manager() as m:
+        ret = m.dict()
+        _watch(mp.spawn(_worker, args=(1, _free_port(), "spce", True, ret, "nccl", True, None, (2,), "half", 0, None, True), nprocs=1, join=False))
         r = ret[0]
     assert r["err"] < 1e-5 and r["err_moved"] < 1e-5, r
     assert abs(r["e_lj"] - r["e_lj_ref"]) < 1e-5 * abs(r["e_lj_ref"]), r

@@ -121,8 +121,16 @@ def test_exclusion_dense_mixture_is_complete():
 
 def test_list_statistics_match_the_reference_at_97k():
     """the reference's own list for this system (5x5x6 spc216, rlist 1.0) has 1570
-    super-clusters, nsci 2593, ncj4 53,638, 1,042,421 cluster pairs, nexcl 15,786.  Our builder
-    sorts ties differently, so the numbers agree to a few percent, not exactly."""
+    super-clusters, nsci 2593, ncj4 53,638, 1,042,421 cluster pairs, nexcl 15,786.  Those are the numbers of mdrun's
+    start configuration (genconf's box after grompp, as the md.log of that run prints them), which this image cannot
+    regenerate: the number of super-clusters is fixed by how many atoms fall into each of the 10 x 10 columns
+    (a column of 973 atoms takes 16 super-cells, one of 960 takes 15), i.e. by the coordinates alone, and the raw
+    spc216 tiling built here populates the columns differently (1,550 super-cells against 1,570: 50 of the 100
+    columns hold more than 960 atoms here, 70 did there).  So the counts agree to a few
+    percent and cannot agree exactly; it is the coordinates that differ, not the rules.  The rules themselves --
+    column count, column of an atom, the z / y / x order with its backward halves, tie order, fillers, j-cell order,
+    masks, diagonal exclusions, sort_sci -- are held to the reference EXACTLY on a toy system in
+    tests/test_list_rules.py."""
     s = g.system.water_box(5, 5, 6)
     ip = g.system.reaction_field(1.0)
     p = g.workload.prepare(s, ip)
