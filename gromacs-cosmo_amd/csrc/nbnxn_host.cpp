@@ -730,6 +730,12 @@ int nbnxn_host_make_pairlist_zones(nbnxn_host_ptr_t h, int iloc, int nzp, const 
         {
             return fail("zone pair %d = {%d, %d, %d} outside the %zu gridded zones", z, iz, j0, j1, h->grids.size());
         }
+        // one row per i-zone, i-zones ascending, as in the reference's tables (domdec.c:433-449): the entries of the list
+        // come out in table order here and in i-cell order in the device builder, which must give the same list
+        if (z > 0 && iz <= zone_pairs[3 * (z - 1)])
+        {
+            return fail("zone pair %d: i-zone %d after i-zone %d: the table lists every i-zone once, ascending", z, iz, zone_pairs[3 * (z - 1)]);
+        }
     }
     for (int d = 0; d < 3; d++)
     {

@@ -1233,6 +1233,11 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, int nzp, c
             {
                 return sfail("zone pair %d = {%d, %d, %d} outside the %d gridded zones", z, iz, j0, j1, s->nzones);
             }
+            // one row per i-zone, ascending (domdec.c:433-449), as the host builder demands: both then give the same list
+            if (z > 0 && iz <= zone_pairs[3 * (z - 1)])
+            {
+                return sfail("zone pair %d: i-zone %d after i-zone %d: the table lists every i-zone once, ascending", z, iz, zone_pairs[3 * (z - 1)]);
+            }
             if (same)
             {
                 if (nzp != 1 || iz != 0 || j0 != 0 || j1 != 1) { return sfail("the local list is the zone pair {0, 0, 1}"); }

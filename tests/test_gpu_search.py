@@ -440,7 +440,8 @@ def test_device_search_with_zone_pairs(nb, self_dims, grid=(1, 1, 1), rank=0):
         # i-clusters of imported zones are in the list
         assert dom.pl_nonlocal.sci["sci"].max() * 64 >= dom.npad_local
     # tables the device search does not take
-    for iloc, zp in ((abi.LOCAL, ((0, 0, 2),)), (abi.NONLOCAL, ((1, 1, 2),)), (abi.NONLOCAL, ((0, 0, 2),)), (abi.NONLOCAL, ((0, 1, 99),))):
+    for iloc, zp in ((abi.LOCAL, ((0, 0, 2),)), (abi.NONLOCAL, ((1, 1, 2),)), (abi.NONLOCAL, ((0, 0, 2),)), (abi.NONLOCAL, ((0, 1, 99),)),
+                     (abi.NONLOCAL, ((1, 2, 2), (0, 1, 2))), (abi.NONLOCAL, ((0, 1, 2), (0, 1, 2)))):   # i-zones not ascending / listed twice
         with pytest.raises(g.gpu.HipError):
             nb.make_pairlist(dom.rlist, None, None, dom.min_ci_balanced, iloc=iloc, zone_pairs=zp)
 

@@ -166,6 +166,13 @@ def test_errors_are_reported_not_crashed():
         h.make_pairlist(abi.LOCAL, 1.0, xq)   # box shorter than 2*rlist
     with pytest.raises(g.host.HostError):
         h.set_atomdata(3, s.type + 5, s.q)    # type outside the table
+    # zone-pair tables list every i-zone once, ascending (domdec.c:433-449); anything else would give the host and the
+    # device builder differently ordered lists, so both refuse it
+    ip = g.system.reaction_field(0.9)
+    for zp in (((0, 0, 1), (0, 0, 1)), ((0, 0, 2),), ((1, 0, 1),)):
+        with pytest.raises(g.host.HostError):
+            h.make_pairlist(abi.LOCAL, 0.9, xq, zone_pairs=zp)
+    assert h.make_pairlist(abi.LOCAL, 0.9, xq, zone_pairs=((0, 0, 1),)).nsci > 0
 
 
 @pytest.mark.parametrize("skew,rc,wide", [((6, -5, 4), 0.9, True), ((3, 2, -6), 0.8, False), ((0, 0, 5), 0.9, False)])

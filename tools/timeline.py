@@ -82,3 +82,5 @@ for lo, hi in zip(edges[:-1], edges[1:]):
         continue
     print(f"  start {lo:5.1f}-{hi:5.1f} us: {int(m.sum()):5d}  {ncj4[m].mean():6.1f}  {e_live[m].sum() / max(ncj4[m].sum(), 1):8.2f}"
           f"  {loop[m].sum() / max(ncj4[m].sum(), 1):10.2f}  {1e3 * loop[m].sum() / max(e_live[m].sum(), 1):10.1f}    {pro[m].mean():6.2f}  {epi[m].mean():6.2f}")
+if os.environ.get("TIMELINE_DUMP"):
+    np.savez_compressed(os.environ["TIMELINE_DUMP"], t=t, ncj4=ncj4, hw=hw, cyc=cyc, e_live=e_live, e_j=e_j)
