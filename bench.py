@@ -126,14 +126,19 @@ def mixture_leg(g, abi, peak_tflops, sizes=(100000, 3000000)):
                 nb.clear_outputs(fl); nb.launch_kernel_resident(fl)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) * 1e3 / n
-            lds = 4100 + p.ntype * (1168 if name.endswith("ljpme") else 544)
+            # the library's rule (lds_table_max_types, nbnxn_kernel.hip): plain LJ up to 16 types, LJ-PME up to 6
+            ljpme = name.endswith("ljpme")
+            cap = int(os.environ.get("GMX_HIP_NB_LDS_TABLE_MAX_TYPES", 6 if ljpme else 16))
+            in_lds = p.ntype <= min(cap, 16)
+            lds = 4100 + (p.ntype * (1168 if ljpme else 544) if in_lds else 0)
             out[f"{name}_{natoms}"] = {"atoms": s.natoms, "ntype": int(p.ntype), "pair_slots_per_step": p.pair_slots, "nsci": p.pl.nsci, "nexcl": p.pl.nexcl,
                                        "ms_per_step": ms, "pairs_per_s": p.pair_slots / (ms * 1e-3),
                                        "roofline_frac": p.pair_slots * FLOPS[("ewald", True)] / (ms * 1e-3) / 1e12 / peak_tflops,
-                                       "lds_bytes_per_workgroup": lds}
+                                       "lj_table": "lds" if in_lds else "global", "lds_bytes_per_workgroup": lds}
     nb.close()
     out["note"] = ("wall time per step of back-to-back launches; roofline_frac by nrnb's 107 flops per pair slot as for the headline (LJ-PME costs more "
-                   "than that per pair, so its fraction understates it); 9 atom types: the LDS table is in use (tools/lds_threshold_scan.py for where it stops paying)")
+                   "than that per pair, so its fraction understates it); 9 atom types: the per-entry LJ table is in LDS for plain LJ and in global memory for LJ-PME "
+                   "(the measured switch points: tools/lds_threshold_scan.py, profiles/r3_b_lds_threshold.txt)")
     return out
 
 
