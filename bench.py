@@ -607,7 +607,7 @@ def main():
     # figure measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command is kept
     # under profiles/ and quoted only when the workload is the one it was measured on
     traffic = None
-    tname = "r3_c_hbm_traffic.json"
+    tname = "r3_f_hbm_traffic.json"
     tpath = os.path.join(ROOT, "profiles", tname)
     if not decomposed and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
             and os.path.exists(tpath):

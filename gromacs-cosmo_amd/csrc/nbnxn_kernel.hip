@@ -746,6 +746,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long tl_c0 = __builtin_amdgcn_s_memtime();
 #endif
+    // the sci entry heads the longest chain of dependent requests of the prologue (entry -> first group -> j-atoms): it is
+    // the first thing asked for, in the same batch of kernel arguments as the table below
+#ifdef NBX_DBG_SAME_ENTRY   // timing experiments only: every wave walks one of the first 64 (largest) entries: everything in cache
+    const nbx_sci_t e     = a.sci[blockIdx.x & 63];
+#else
+    const nbx_sci_t e     = a.sci[blockIdx.x];
+#endif
     const int       ntype = a.ntype;
 #if NBX_PRO2
     // the type-pair table depends on nothing but the kernel arguments: requested first, it arrives while the entry,
@@ -767,11 +774,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
         }
     }
 #endif
-#ifdef NBX_DBG_SAME_ENTRY   // timing experiments only: every wave walks one of the first 64 (largest) entries: everything in cache
-    const nbx_sci_t e     = a.sci[blockIdx.x & 63];
-#else
-    const nbx_sci_t e     = a.sci[blockIdx.x];
-#endif
     const int       sci   = e.sci;
     const bool      central = (e.shift == NBX_CENTRAL);
 
@@ -789,9 +791,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
 
     nbx_jhdr_t  cur;
     nbx_jslot_t sa, sb;
-    cur.imask = 0; cur.wexcl = 0xffffffffu;
-    cur.cj[0] = cur.cj[1] = cur.cj[2] = cur.cj[3] = 0;
-    if (e.cj4_ind_start < e.cj4_ind_end) { load_jhdr(a, e.cj4_ind_start, lane, cur); }
+    // The first group's words are REQUESTED here and decoded below: the entry's own atoms, their types and the shift
+    // vector hang on the sci entry alone, so they go out before the wave waits for the group (round 3; they used to be
+    // requested behind that wait, one round trip later, and the LDS staging of the i-atoms and of the LJ rows then stood
+    // between the arrival of the first j-atoms and the first pair instead of beside their flight).
+    // (the two kernel arguments the decode below needs are fetched early: left alone the compiler fetched them in a round
+    // trip of their own between the first group's arrival and the request for its j-atoms.  Only by-value uses: naming a
+    // pointer argument in an asm operand takes its loads off the scalar path.)
+    {
+        const unsigned long long excl_bits = reinterpret_cast<unsigned long long>(p_excl);
+        __asm__ volatile("" : : "s"(excl_bits), "s"(p_k.qscale));
+    }
+    const nbx_f32x4 vi  = nbx_buffer_load_f32x4(js.rx, lane * 16, sci * 1024, 0);
+    int             ti  = nbx_buffer_load_i32(js.rt, lane * 4, sci * 256, 0);
+    const float     shx = a.shift_vec[3 * e.shift + 0], shy = a.shift_vec[3 * e.shift + 1], shz = a.shift_vec[3 * e.shift + 2];
+    nbx_jraw_t raw0;
+    raw0.w0 = make_int4(0, 0, 0, 0); raw0.w1 = make_int4(0, 0, 0, 0);
+    if (e.cj4_ind_start < e.cj4_ind_end) { load_jraw(a, e.cj4_ind_start, raw0); }
+    decode_jhdr(a, raw0, lane, cur);
     load_jslot(js, cur.cj[0], sa);
 #if NBX_JAHEAD3
     nbx_jslot_t sc, sd;
@@ -799,15 +816,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
     load_jslot(js, cur.cj[2], sc);
 #endif
 
-    int ti;
+    // Ewald: the scaled coordinates are x' = fma(x, beta, C) with C = -fl(beta * o), o the entry's first (shifted)
+    // i-atom.  The product is exact inside the fma and C is the SAME number for every i- and j-atom of the entry, so
+    // it cancels in x_i' - x_j': what is left is the rounding of two numbers of local magnitude (ulp(beta * 3 nm)),
+    // where scaling the raw coordinates would round at ulp(beta |x|) and cost ~1e-5 of force accuracy.
+    float ox = 0, oy = 0, oz = 0;
     {
-        const nbx_f32x4 v = nbx_buffer_load_f32x4(js.rx, lane * 16, sci * 1024, 0);
-        ti                = nbx_buffer_load_i32(js.rt, lane * 4, sci * 256, 0);
         float4 x;
-        x.x = v.x + a.shift_vec[3 * e.shift + 0];
-        x.y = v.y + a.shift_vec[3 * e.shift + 1];
-        x.z = v.z + a.shift_vec[3 * e.shift + 2];
-        x.w = v.w * a.k.qscale;
+        x.x = vi.x + shx;
+        x.y = vi.y + shy;
+        x.z = vi.z + shz;
+        x.w = vi.w * a.k.qscale;
+        if (EL != NBX_EL_RF)
+        {
+            // o is lane 0's atom: taken from its registers, no trip through LDS
+            ox = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x.x))) * a.k.xscale);
+            oy = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x.y))) * a.k.xscale);
+            oz = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x.z))) * a.k.xscale);
+            // the pair loop reads the rows from LDS (xi_in_lds): they are staged scaled, once
+            if (xi_in_lds(EL)) { x.x = fmaf(x.x, a.k.xscale, ox); x.y = fmaf(x.y, a.k.xscale, oy); x.z = fmaf(x.z, a.k.xscale, oz); }
+        }
         s_xqi[lane] = x;
         if (NBFP_LDS)
         {
@@ -863,31 +891,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
     }
     else if (ENER && VMOD == 3) { c6ii = a.nbfp[ti * ntype + ti].x * (EL != NBX_EL_RF ? a.k.c6scale : 1.0f); }
 
-    // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry;
-    // (global-table path: their types are packed one per byte)
-    // Ewald: the scaled coordinates are x' = fma(x, beta, C) with C = -fl(beta * o), o the entry's first (shifted)
-    // i-atom.  The product is exact inside the fma and C is the SAME number for every i- and j-atom of the entry, so
-    // it cancels in x_i' - x_j': what is left is the rounding of two numbers of local magnitude (ulp(beta * 3 nm)),
-    // where scaling the raw coordinates would round at ulp(beta |x|) and cost ~1e-5 of force accuracy.
-    float ox = 0, oy = 0, oz = 0;
-    if (EL != NBX_EL_RF)
-    {
-        const float4 o = s_xqi[0];
-        ox = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x))) * a.k.xscale);
-        oy = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y))) * a.k.xscale);
-        oz = -(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z))) * a.k.xscale);
-    }
+    // this lane's eight i-atoms (one per i-cluster) stay in registers for the whole entry, or are read from LDS per
+    // pair (xi_in_lds); (global-table path: their types are packed one per byte)
     float4   xi[8];
     unsigned tlo = 0, thi = 0;
     float    fix[8], fiy[8], fiz[8];
-    if (xi_in_lds(EL) && EL != NBX_EL_RF)
-    {
-        // every lane scales the atom it staged; the pair loop reads the scaled rows
-        float4 x = s_xqi[lane];
-        x.x = fmaf(x.x, a.k.xscale, ox); x.y = fmaf(x.y, a.k.xscale, oy); x.z = fmaf(x.z, a.k.xscale, oz);
-        wave_lds_sync();
-        s_xqi[lane] = x;
-    }
 #pragma unroll
     for (int i = 0; i < 8; i++)
     {
