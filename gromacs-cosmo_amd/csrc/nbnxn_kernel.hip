@@ -47,6 +47,13 @@ __device__ int       nbx_buffer_load_i32(nbx_i32x4 rsrc, int voffset, int soffse
 // v_writelane_b32: lane `lane` of the result is val, the others keep old
 __device__ int       nbx_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
+// a 16-byte LDS read the compiler neither moves nor splits (volatile, in the LDS address space)
+__device__ __forceinline__ nbx_f32x4 lds_load_f32x4_volatile(const float4 *p)
+{
+    typedef const volatile nbx_f32x4 __attribute__((address_space(3))) *lds_ptr_t;
+    return *(lds_ptr_t)(p);
+}
+
 #ifndef NBX_KERNEL_WAVES
 #define NBX_KERNEL_WAVES 4
 #endif
@@ -65,9 +72,6 @@ __device__ int       nbx_writelane(int val, int lane, int old) __asm("llvm.amdgc
 #ifndef NBX_FJ_CAP
 #define NBX_FJ_CAP 32
 #endif
-#ifndef NBX_JAHEAD3
-#define NBX_JAHEAD3 0
-#endif
 #ifndef NBX_CPAIR
 #define NBX_CPAIR 0
 #endif
@@ -75,20 +79,27 @@ __device__ int       nbx_writelane(int val, int lane, int old) __asm("llvm.amdgc
 #define NBX_JRED2 1
 #endif
 #ifndef NBX_XI_LDS
-#define NBX_XI_LDS 2     // i-atoms read from LDS per pair instead of held in 32 registers: 0 never, 1 always, 2 Ewald flavours
+#define NBX_XI_LDS 1     // i-atoms read from LDS per pair instead of held in 32 registers: 0 never, 1 always, 2 Ewald flavours
 #endif
+#ifndef NBX_PLAIN_GROUPS
+#define NBX_PLAIN_GROUPS 1   // groups without exclusion words and diagonal cluster pairs take a pair body without the mask work
+#endif
+#ifndef NBX_RF_VGPR
+#define NBX_RF_VGPR 0        // reaction field: -2 k_rf in a VGPR (the pair's force fma then has no SGPR operand): measured, no gain
+#endif
+#ifndef NBX_XI_PREFETCH
+#define NBX_XI_PREFETCH 2    // i-atoms in LDS: the next pair's row is requested a pair ahead, unconditionally: 0 never, 1 always,
+#endif                       // 2 where it was measured to pay (reaction field; Ewald force-only: -2 %; Ewald with energies: +1 %)
 #ifndef NBX_KERNEL_WAVES_EW
-#define NBX_KERNEL_WAVES_EW 5    // waves per SIMD the Ewald flavours are compiled for (5 needs <= 96 registers)
+#define NBX_KERNEL_WAVES_EW 5    // waves per SIMD the flavours with their i-atoms in LDS are compiled for (5 needs <= 96 registers)
 #endif
 constexpr bool xi_in_lds(int el) { return NBX_XI_LDS == 1 || (NBX_XI_LDS == 2 && el != NBX_EL_RF); }
+constexpr bool xi_prefetch(int el, bool ener) { return xi_in_lds(el) && (NBX_XI_PREFETCH == 1 || (NBX_XI_PREFETCH == 2 && (el == NBX_EL_RF || !ener))); }
 // (the global-table instantiations, more than 16 atom types, keep 4 waves: at 96 registers some of them spill)
 constexpr int  kernel_waves(int el, bool ener, bool lds_table)
 {
-    return el != NBX_EL_RF && NBX_XI_LDS == 2 && lds_table ? NBX_KERNEL_WAVES_EW : (ener ? NBX_KERNEL_WAVES : NBX_KERNEL_WAVES_F);
+    return xi_in_lds(el) && lds_table ? NBX_KERNEL_WAVES_EW : (ener ? NBX_KERNEL_WAVES : NBX_KERNEL_WAVES_F);
 }
-#if NBX_JAHEAD3 && !NBX_HDR2
-#error "NBX_JAHEAD3 needs the next group's header at the top of the iteration (NBX_HDR2)"
-#endif
 
 
 namespace {
@@ -265,18 +276,26 @@ __device__ __forceinline__ float and_mask(const float v, const int m)
     return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
 }
 
-template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD>
+// constants of the pair body kept in VGPRs: a VALU instruction with an SGPR operand issues at half rate
+// (tools/ubench/valu_mix.hip)
+struct nbx_vconst_t {
+    float r2inc;       // the r^2 increment (see pair_interaction)
+    float m_two_k_rf;  // -2 k_rf (reaction-field flavours)
+};
+
+template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool PLAIN>
 __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, const float4 xi, const float4 xj,
                                         const float2 c, const float c6g, const unsigned wexcl, const int bitpos, const bool allowed,
-                                        const float r2inc,
+                                        const nbx_vconst_t &vc,
                                         float &fix, float &fiy, float &fiz, float &fjx, float &fjy, float &fjz,
                                         nbx_eacc_t &acc, bool &any_in_rlist)
 {
     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-    // 0 for an excluded pair, all ones otherwise
-    int         m;
+    // 0 for an excluded pair, all ones otherwise.  PLAIN: the group has no exclusion word and no diagonal cluster pair
+    // (nbx_jhdr_t::plain), so the mask is a constant and every and_mask() below folds away
+    int         m = -1;
     // (as asm: left to itself the compiler turns it into v_and + v_cmp + v_cndmask)
-    __asm__("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(wexcl), "n"(bitpos));
+    if (!PLAIN) { __asm__("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(wexcl), "n"(bitpos)); }
     // the reference's r^2 += (1 - int_bit) * NBNXN_AVOID_SING_R2_INC (nbnxn_consts.h:66-79,
     // nbnxn_cuda_kernel.cuh:371, nbnxn_kernel_ref_inner.h:132): two distinct, mutually excluded atoms may sit on
     // one point (shells, virtual sites); their Ewald / reaction-field / LJ-PME correction must stay finite.  Here the
@@ -284,12 +303,12 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     // interacts it is below half an ulp of r^2 from r = 0.005 nm on (1e-12 / r^2 < 2^-25), far inside any LJ core, so
     // those pairs get the same float r^2 as without it and the mask instruction of the selective form is saved; it is
     // also far below an ulp of rc^2 / rlist^2, so cut-off and pruning decisions are the reference's.
-    const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, r2inc)));
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, vc.r2inc)));
     if (PRUNE) { any_in_rlist = __any(r2 < a.k.rlist2); }
     // The cut-off and the j > i rule of a diagonal cluster pair go into the EXEC mask: lanes outside take no part in
     // what follows, so nothing below selects on the cut-off or multiplies by a 0 / 1 factor, and values that would
     // overflow there (filler atoms sit thousands of nm away) are never computed.
-    if (!((r2 < a.k.rc2) && allowed)) { return; }
+    if (!((r2 < a.k.rc2) && (PLAIN || allowed))) { return; }
     const float inv_r  = __builtin_amdgcn_rsqf(r2);
     if (VMOD == 0 && !VDWC && ENER)
     {
@@ -307,7 +326,7 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
         float       F, ec;
         if (EL == NBX_EL_RF)
         {
-            F  = fmaf(qq, -a.k.two_k_rf, t);
+            F  = fmaf(qq, vc.m_two_k_rf, t);
             ec = inv_rm + fmaf(0.5f * a.k.two_k_rf, r2, -a.k.c_rf);   // c_rf also goes with excluded pairs
         }
         else
@@ -412,7 +431,7 @@ __device__ __forceinline__ void pair_interaction(const nbx_kernel_view_t &a, con
     }
     if (VDWC && ENER) { elj = vdw_in_range ? elj : 0.0f; }
     float F, gv = 0.0f;
-    if (EL == NBX_EL_RF) { F = fmaf(qq, -a.k.two_k_rf, t); }
+    if (EL == NBX_EL_RF) { F = fmaf(qq, vc.m_two_k_rf, t); }
     else if (EL == NBX_EL_EWALD_TAB)
     {
         // force table with linear interpolation (nbnxn_cuda_kernel_utils.cuh:304-317); the table
@@ -452,6 +471,7 @@ struct nbx_jhdr_t {
     unsigned imask;
     int      cj[4];
     unsigned wexcl;   // per lane
+    bool     plain;   // wave-uniform: no exclusion word and no j-cluster of the entry's own super-cluster in a central entry
 };
 
 struct nbx_jslot_t {
@@ -509,7 +529,7 @@ __device__ __forceinline__ void load_jraw(const nbx_kernel_view_t &a, int j4, nb
     r.w1 = g[1];
 }
 
-__device__ __forceinline__ void decode_jhdr(const nbx_kernel_view_t &a, const nbx_jraw_t &r, int lane, nbx_jhdr_t &h)
+__device__ __forceinline__ void decode_jhdr(const nbx_kernel_view_t &a, const nbx_jraw_t &r, int lane, const bool central, const int sci, nbx_jhdr_t &h)
 {
     // slots without interaction bits hold undefined j-clusters (nbnxn_search.c:2460-2472): cluster 0 is read for them
     const int4 w0 = r.w0, w1 = r.w1;
@@ -522,6 +542,14 @@ __device__ __forceinline__ void decode_jhdr(const nbx_kernel_view_t &a, const nb
     h.cj[1] = (h.imask & 0x0000ff00u) ? w0.y : 0;
     h.cj[2] = (h.imask & 0x00ff0000u) ? w0.z : 0;
     h.cj[3] = (h.imask & 0xff000000u) ? w0.w : 0;
+#if NBX_PLAIN_GROUPS
+    // Most groups carry no exclusion word and no diagonal cluster pair: they take the pair body without the exclusion
+    // mask and without the j > i rule (PLAIN).  Decided here, one group ahead, on wave-uniform words only.
+    const bool own = central && (((h.cj[0] >> 3) == sci) | ((h.cj[1] >> 3) == sci) | ((h.cj[2] >> 3) == sci) | ((h.cj[3] >> 3) == sci));
+    h.plain = ((ei0 | ei1) == 0) && !own;
+#else
+    h.plain = false;
+#endif
 }
 
 __device__ __forceinline__ void load_jhdr(const nbx_kernel_view_t &a, int j4, int lane, nbx_jhdr_t &h)
@@ -540,6 +568,7 @@ __device__ __forceinline__ void load_jhdr(const nbx_kernel_view_t &a, int j4, in
     h.cj[1] = (h.imask & 0x0000ff00u) ? w0.y : 0;
     h.cj[2] = (h.imask & 0x00ff0000u) ? w0.z : 0;
     h.cj[3] = (h.imask & 0xff000000u) ? w0.w : 0;
+    h.plain = false;
 }
 
 __device__ __forceinline__ void load_jslot(const nbx_jsrc_t &js, int cj, nbx_jslot_t &s)
@@ -569,14 +598,14 @@ constexpr int ljt_pos_bytes(int vmod, bool ener, int pos)
 }
 constexpr int ljt_row_bytes(int vmod, bool ener) { return lds_entry_bytes(vmod, ener) == 8 ? 544 : 1168; }
 
-template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS, int JM>
+template <int EL, bool ENER, bool PRUNE, bool VDWC, int VMOD, bool NBFP_LDS, int JM, bool PLAIN>
 __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float4 (&xi)[8], const unsigned tlo,
                                             const unsigned thi, float (&fix)[8], float (&fiy)[8], float (&fiz)[8],
                                             const nbx_jslot_t &s, const int cj, const unsigned wexcl,
                                             unsigned &imask, const bool central, const int sci, const int tidxi,
                                             const int tidxj, const char *ljt_lane, float *s_fj_lane,
                                             int &cjs, int &nfj, nbx_eacc_t &acc, const float ox, const float oy,
-                                            const float oz, const float r2inc, const float4 *s_xi_lane)
+                                            const float oz, const nbx_vconst_t &vc, const float4 *s_xi_lane)
 {
     if (!(imask & (0xffu << (JM * 8)))) { return; }
     float2 c[8];
@@ -632,6 +661,12 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     // experiment: the LJ entry of a pair is read when the pair is computed (2 live registers instead of 16)
     const char *crow = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
 #endif
+    // i-atoms from LDS (xi_in_lds), xi_prefetch: the row of pair i + 1 is requested at the head of pair i, outside the test of pair
+    // i + 1's mask bit -- as a volatile access, which the compiler neither sinks into the conditional body (where its
+    // whole latency stood between the branch and the first subtraction) nor splits into a 12- and a 4-byte read (8 + 2
+    // LDS cycles where the 16-byte read takes 4, MI355X_MICROARCH.md)
+    nbx_f32x4 xin;
+    if (xi_prefetch(EL, ENER)) { xin = lds_load_f32x4_volatile(s_xi_lane); }
     float4 xj = s.x;
     // Ewald: scaled coordinates relative to the entry's origin, see the kernel
     if (EL != NBX_EL_RF) { xj.x = fmaf(xj.x, a.k.xscale, ox); xj.y = fmaf(xj.y, a.k.xscale, oy); xj.z = fmaf(xj.z, a.k.xscale, oz); }
@@ -640,16 +675,22 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     for (int i = 0; i < 8; i++)
     {
         const unsigned bit = 1u << (JM * 8 + i);
+        float4 xiv = xi[i];
+        if (xi_prefetch(EL, ENER))
+        {
+            xiv = make_float4(xin.x, xin.y, xin.z, xin.w);
+            if (i < 7) { xin = lds_load_f32x4_volatile(s_xi_lane + (i + 1) * 8); }
+        }
         if (imask & bit)
         {
-            const bool diag = central && (cj == sci * 8 + i);
+            const bool diag = !PLAIN && central && (cj == sci * 8 + i);
             bool       any  = true;
 #if NBX_CPAIR
             if (NBFP_LDS && !THIRD) { c[i] = *reinterpret_cast<const float2 *>(crow + 8 * i); cg[i] = 0.0f; }
 #endif
             // Ewald flavours: the i-atoms stay in LDS and are read per pair (xi_in_lds)
-            const float4 xiv = xi_in_lds(EL) ? s_xi_lane[i * 8] : xi[i];
-            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD>(a, xiv, xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, r2inc,
+            if (xi_in_lds(EL) && !xi_prefetch(EL, ENER)) { xiv = s_xi_lane[i * 8]; }
+            pair_interaction<EL, ENER, PRUNE, VDWC, VMOD, PLAIN>(a, xiv, xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, vc,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, acc, any);
             if (PRUNE && !any) { imask &= ~bit; }
         }
@@ -808,13 +849,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
     nbx_jraw_t raw0;
     raw0.w0 = make_int4(0, 0, 0, 0); raw0.w1 = make_int4(0, 0, 0, 0);
     if (e.cj4_ind_start < e.cj4_ind_end) { load_jraw(a, e.cj4_ind_start, raw0); }
-    decode_jhdr(a, raw0, lane, cur);
+    decode_jhdr(a, raw0, lane, central, sci, cur);
     load_jslot(js, cur.cj[0], sa);
-#if NBX_JAHEAD3
-    nbx_jslot_t sc, sd;
-    load_jslot(js, cur.cj[1], sb);
-    load_jslot(js, cur.cj[2], sc);
-#endif
 
     // Ewald: the scaled coordinates are x' = fma(x, beta, C) with C = -fl(beta * o), o the entry's first (shifted)
     // i-atom.  The product is exact inside the fma and C is the SAME number for every i- and j-atom of the entry, so
@@ -918,8 +954,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
 
     // the r^2 increment lives in a VGPR: as the addend of the distance's first fma it would otherwise be an SGPR
     // operand, and a VALU instruction with one issues at half rate (tools/ubench/valu_mix.hip)
-    float r2inc_v;
-    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(r2inc_v) : "s"(a.k.r2inc));
+    nbx_vconst_t vc;
+    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(vc.r2inc) : "s"(a.k.r2inc));
+    vc.m_two_k_rf = 0.0f;
+#if NBX_RF_VGPR
+    if (EL == NBX_EL_RF) { __asm__ volatile("v_mov_b32 %0, %1" : "=v"(vc.m_two_k_rf) : "s"(-a.k.two_k_rf)); }
+#else
+    if (EL == NBX_EL_RF) { vc.m_two_k_rf = -a.k.two_k_rf; }
+#endif
 
     nbx_eacc_t acc;
     if (ENER)
@@ -942,73 +984,77 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
 #ifdef NBX_TIMELINE
     const unsigned long long tl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
-#define NBX_JCLUSTER(JM, SLOT)                                                                             \
-    jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
+#define NBX_JCLUSTER_P(JM, SLOT, PLAIN)                                                                    \
+    jcluster<EL, ENER, PRUNE, VDWC, VMOD, NBFP_LDS, JM, PLAIN>(a, xi, tlo, thi, fix, fiy, fiz, SLOT, cur.cj[JM], cur.wexcl,    \
                                                imask, central, sci, tidxi, tidxj, ljt_lane, s_fj_lane, cjs,  \
-                                               nfj, acc, ox, oy, oz, r2inc_v, s_xqi + tidxi)
+                                               nfj, acc, ox, oy, oz, vc, s_xqi + tidxi)
 #if NBX_HDR2
     // the raw words of the group after the current one, requested a whole group ahead (zeros: no such group)
     nbx_jraw_t raw1;
     raw1.w0 = make_int4(0, 0, 0, 0); raw1.w1 = make_int4(0, 0, 0, 0);
     if (e.cj4_ind_start + 1 < e.cj4_ind_end) { load_jraw(a, e.cj4_ind_start + 1, raw1); }
 #endif
-    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++)
-    {
-        // software pipeline: the next group's list words are requested before this group's
-        // arithmetic starts, each j-cluster's atoms one j-cluster ahead
-        nbx_jhdr_t nxt;
+    // One iteration of the group loop.  Software pipeline: the next group's list words are requested before this
+    // group's arithmetic starts, each j-cluster's atoms one j-cluster ahead.
+    // A scalar load that is consumed right away (the exclusion word's address and the j-cluster indices hang on it)
+    // parks the wave for a scalar-cache or L2 round trip once per group.  So the group after next is REQUESTED here and
+    // the next group, requested one iteration ago, is decoded from registers (all-zero words give an empty group: no
+    // interaction bits, cluster 0, no exclusion word).
 #if NBX_HDR2
-        // A scalar load that is consumed right away (the exclusion word's address and the j-cluster indices hang on
-        // it) parks the wave for a scalar-cache or L2 round trip once per group.  So the group after next is REQUESTED
-        // here and the next group, requested one iteration ago, is decoded from registers (all-zero words give an
-        // empty group: no interaction bits, cluster 0, no exclusion word).
-        decode_jhdr(a, raw1, lane, nxt);
-        nbx_jraw_t raw2;
-        raw2.w0 = make_int4(0, 0, 0, 0); raw2.w1 = make_int4(0, 0, 0, 0);
+#define NBX_ITER_HEAD                                                                                      \
+        decode_jhdr(a, raw1, lane, central, sci, nxt);                                                     \
+        nbx_jraw_t raw2;                                                                                   \
+        raw2.w0 = make_int4(0, 0, 0, 0); raw2.w1 = make_int4(0, 0, 0, 0);                                  \
         if (j4 + 2 < e.cj4_ind_end) { load_jraw(a, j4 + 2, raw2); }
+#define NBX_ITER_TAIL raw1 = raw2;
 #else
-        nxt.imask = 0; nxt.wexcl = 0xffffffffu;
-        nxt.cj[0] = nxt.cj[1] = nxt.cj[2] = nxt.cj[3] = 0;
+#define NBX_ITER_HEAD                                                                                      \
+        nxt.imask = 0; nxt.wexcl = 0xffffffffu; nxt.plain = false;                                         \
+        nxt.cj[0] = nxt.cj[1] = nxt.cj[2] = nxt.cj[3] = 0;                                                 \
         if (j4 + 1 < e.cj4_ind_end) { load_jhdr(a, j4 + 1, lane, nxt); }
+#define NBX_ITER_TAIL
 #endif
-
-        unsigned imask = cur.imask;
-#if NBX_JAHEAD3
-        // experiment: j-atoms requested three j-clusters ahead (four rolling register sets)
-        load_jslot(js, cur.cj[3], sd);
-        NBX_JCLUSTER(0, sa);
-        load_jslot(js, nxt.cj[0], sa);
-        NBX_JCLUSTER(1, sb);
-        load_jslot(js, nxt.cj[1], sb);
-        NBX_JCLUSTER(2, sc);
-        load_jslot(js, nxt.cj[2], sc);
-        NBX_JCLUSTER(3, sd);
-#else
-        load_jslot(js, cur.cj[1], sb);
-        NBX_JCLUSTER(0, sa);
-        load_jslot(js, cur.cj[2], sa);
-        NBX_JCLUSTER(1, sb);
-        load_jslot(js, cur.cj[3], sb);
-        NBX_JCLUSTER(2, sa);
-        load_jslot(js, nxt.cj[0], sa);
-        NBX_JCLUSTER(3, sb);
-#endif
-
-        if (PRUNE)
-        {
-            if (lane == 0)
-            {
-                a.cj4[j4].imei[0].imask = imask;
-                a.cj4[j4].imei[1].imask = imask;
-            }
-        }
-        cur = nxt;
-#if NBX_HDR2
-        raw1 = raw2;
-#endif
-        if (nfj > FJ_CAP - 4) { flush_fj(a.f, s_fj, cjs, nfj, lane); nfj = 0; }
+#define NBX_ITER(PLAIN)                                                                                    \
+    {                                                                                                      \
+        nbx_jhdr_t nxt;                                                                                    \
+        NBX_ITER_HEAD                                                                                      \
+        unsigned imask = cur.imask;                                                                        \
+        load_jslot(js, cur.cj[1], sb);                                                                     \
+        NBX_JCLUSTER_P(0, sa, PLAIN);                                                                      \
+        load_jslot(js, cur.cj[2], sa);                                                                     \
+        NBX_JCLUSTER_P(1, sb, PLAIN);                                                                      \
+        load_jslot(js, cur.cj[3], sb);                                                                     \
+        NBX_JCLUSTER_P(2, sa, PLAIN);                                                                      \
+        load_jslot(js, nxt.cj[0], sa);                                                                     \
+        NBX_JCLUSTER_P(3, sb, PLAIN);                                                                      \
+        if (PRUNE)                                                                                         \
+        {                                                                                                  \
+            if (lane == 0)                                                                                 \
+            {                                                                                              \
+                a.cj4[j4].imei[0].imask = imask;                                                           \
+                a.cj4[j4].imei[1].imask = imask;                                                           \
+            }                                                                                              \
+        }                                                                                                  \
+        cur = nxt;                                                                                         \
+        NBX_ITER_TAIL                                                                                      \
+        if (nfj > FJ_CAP - 4) { flush_fj(a.f, s_fj, cjs, nfj, lane); nfj = 0; }                            \
     }
-#undef NBX_JCLUSTER
+#if NBX_PLAIN_GROUPS
+    // Runs of groups with (cur.plain false) and without exclusion words / diagonal cluster pairs alternate: two loops
+    // in sequence inside an outer loop, NOT an if / else inside one loop -- over a diamond the register allocator kept
+    // two copies of the 24 i-force accumulators and spilled; through loops that follow each other they stay put.
+    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end;)
+    {
+        for (; j4 < e.cj4_ind_end && !cur.plain; j4++) NBX_ITER(false)
+        for (; j4 < e.cj4_ind_end && cur.plain; j4++) NBX_ITER(true)
+    }
+#else
+    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++) NBX_ITER(false)
+#endif
+#undef NBX_ITER
+#undef NBX_ITER_HEAD
+#undef NBX_ITER_TAIL
+#undef NBX_JCLUSTER_P
     if (nfj > 0) { flush_fj(a.f, s_fj, cjs, nfj, lane); }
 #ifdef NBX_TIMELINE
     const unsigned long long tl_t2 = __builtin_amdgcn_s_memrealtime();
