@@ -21,6 +21,7 @@ list lifetime in the reference.  pair interactions = cluster pairs in the upload
 the reference's counting convention (nbnxn_search.c:5770-5777), NOT the pruned count.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -607,8 +608,9 @@ def main():
     # figure measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command is kept
     # under profiles/ and quoted only when the workload is the one it was measured on
     traffic = None
-    tname = "r3_f_hbm_traffic.json"
-    tpath = os.path.join(ROOT, "profiles", tname)
+    # (the newest pass of tools/profile_round.sh + tools/collect_profiles.py)
+    tpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))[-1]
+    tname = os.path.basename(tpath)
     if not decomposed and args.workload == "ewald" and ener and tiles == (5, 5, 6) and args.mcb < 0 and not args.no_split \
             and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]

@@ -32,10 +32,14 @@ def test_counted_flops_belong_to_the_kernel_source_in_the_tree():
 
 
 def test_traffic_profile_is_committed():
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    name = src.split('tname = "')[1].split('"')[0]
-    d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    """bench.py quotes the newest profiles/r*_hbm_traffic.json: it must belong to the same profiling pass as the counted
+    flops of the kernel source in the tree (tools/profile_round.sh + tools/collect_profiles.py write both)"""
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))[-1]
+    d = json.load(open(path))
     assert d["hbm_bytes_per_launch"] == 1000 * (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"])
+    cf = bench.counted_flops("ewald", True)
+    assert cf is not None and cf["file"].split("_pmc_flops")[0] == os.path.basename(path).split("_hbm_traffic")[0]
 
 
 def test_parity_block_quotes_the_reference_kernels_fixture():
