@@ -232,6 +232,7 @@ def pcie_step_leg(g, abi, prep, ip, flags, nsteps=200):
     import time
     nb = g.gpu.NbnxnHip(0)
     nb.set_timing(False)
+    nb.set_clear_in_kernel(True)      # as include/nbnxn_hip_gmx.h's nbnxn_cuda_init sets it: clear_outputs only flips buffers
     g.workload.upload(nb, prep, ip)
     held = []
 
@@ -266,7 +267,8 @@ def pcie_step_leg(g, abi, prep, ip, flags, nsteps=200):
     return {"ms_per_step": ms, "pairs_per_s": prep.pair_slots / (ms * 1e-3), "steps": nsteps,
             "h2d_bytes_per_step": int(prep.xq.nbytes), "d2h_bytes_per_step": int(prep.natoms * 12 + (2 + 45 * 3) * 4),
             "note": "clear_outputs -> launch_kernel(host xq) -> launch_cpyback -> wait_gpu every step, pinned host arrays, "
-                    "one blocking wait per step: the reference's calling convention (sim_util.c:622, 1147, 1385)"}
+                    "one blocking wait per step: the reference's calling convention (sim_util.c:622, 1147, 1385); xq in and "
+                    "f + partial-sum slots out move by copy kernels on the mapped host arrays (NBNXN_HIP_COPY_KERNELS=0: copy engine)"}
 
 
 def verlet_loop_leg(g, abi, system, ip, flags, nstlist=10, nsteps=100):

@@ -210,6 +210,8 @@ struct nbnxn_hip {
     DevBuf<int>   d_type_in, d_excl_index, d_excl_a;   // caller-order types; topology exclusions (CSR)
     DevBuf<float> d_q_in;
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
+    void  *h_stage_dev = nullptr;   // the device's view of h_stage (pinned + mapped), for the copy kernels
+    bool   copy_kernels = true;     // nbnxn_hip_set_copy_kernels
     // domain decomposition over RCCL (nbnxn_hip_dd_*): one pulse along one dimension
     ncclComm_t    dd_comm = nullptr;
     int           dd_rank = -1, dd_nranks = 0;
@@ -584,6 +586,54 @@ inline bool kernel_calc_ener(int flags)
     return (((flags & NBX_FORCE_VIRIAL) != 0) || b.always_ener) && !b.never_ener;
 }
 
+// ---- host <-> device moves of the per-step arrays by a kernel instead of the copy engine ----
+// The reference's calling convention moves xq in and f (+ energies, shift forces) out every step (nbnxn_cuda.cu:347-348,
+// 492-522).  Through hipMemcpyAsync each of those copies has a floor of ~10 us on this stack and the payload then moves
+// at 32-36 GB/s (profiles/r3_c_copy_split_probe.txt): 43 + 37 + 16 us around a 63 us kernel.  When the caller's arrays
+// are pinned AND mapped into the device's address space -- what nbnxn_hip_pmalloc / the reference's nbat->alloc hook
+// give, and what hipHostRegister gives -- a kernel can read and write them directly: no engine hand-over, and the
+// force copy and the copy of the partial-sum slots become ONE launch.  Pageable or unaligned arrays keep the copy engine.
+// NBNXN_HIP_COPY_KERNELS=0 switches the kernels off (A/B measurements).
+typedef float nbx_copy_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) nbx_copy16_kernel(nbx_copy_f32x4 *__restrict__ dst0, const nbx_copy_f32x4 *__restrict__ src0, const int n0,
+                                                         nbx_copy_f32x4 *__restrict__ dst1, const nbx_copy_f32x4 *__restrict__ src1, const int n1)
+{
+    // (nontemporal: the rows are touched once; the force array's lines need not stay in L2 on their way out)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n0) { __builtin_nontemporal_store(__builtin_nontemporal_load(&src0[i]), &dst0[i]); }
+    else if (i - n0 < n1) { __builtin_nontemporal_store(__builtin_nontemporal_load(&src1[i - n0]), &dst1[i - n0]); }
+}
+
+bool copy_kernels_default()
+{
+    static const bool on = !(getenv("NBNXN_HIP_COPY_KERNELS") && atoi(getenv("NBNXN_HIP_COPY_KERNELS")) == 0);
+    return on;
+}
+
+// the device's view of a pinned, mapped host array, or nullptr (pageable memory, device memory, unknown pointers)
+void *device_view_of_host(const nbnxn_hip *nb, const void *p)
+{
+    if (!p || !nb->copy_kernels) { return nullptr; }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) { return nullptr; }
+    return at.devicePointer;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// dst0[0, bytes0) = src0, dst1[0, bytes1) = src1 in one launch on st; all pointers device-visible and 16-byte aligned,
+// byte counts multiples of 16 (the callers check)
+int copy16(hipStream_t st, void *dst0, const void *src0, size_t bytes0, void *dst1 = nullptr, const void *src1 = nullptr, size_t bytes1 = 0)
+{
+    const int n0 = (int)(bytes0 / 16), n1 = (int)(bytes1 / 16);
+    if (n0 + n1 == 0) { return 0; }
+    hipLaunchKernelGGL(nbx_copy16_kernel, dim3((n0 + n1 + 255) / 256), dim3(256), 0, st, (nbx_copy_f32x4 *)dst0, (const nbx_copy_f32x4 *)src0, n0,
+                       (nbx_copy_f32x4 *)dst1, (const nbx_copy_f32x4 *)src1, n1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
 {
     if (check_loc(iloc)) { return 1; }
@@ -607,7 +657,10 @@ int launch_impl(nbnxn_hip *nb, const float *h_xq, int flags, int iloc)
         if (nb->do_time) { HIP_TRY(hipEventRecord(nb->h2d_start[iloc], st)); }
         if (len > 0)
         {
-            HIP_TRY(hipMemcpyAsync(nb->xq.p + begin, h_xq + (size_t)begin * 4, (size_t)len * sizeof(float4), hipMemcpyHostToDevice, st));
+            const float *src  = h_xq + (size_t)begin * 4;
+            const void  *dsrc = aligned16(src) ? device_view_of_host(nb, src) : nullptr;
+            if (dsrc) { if (copy16(st, nb->xq.p + begin, dsrc, (size_t)len * sizeof(float4))) { return 1; } }
+            else { HIP_TRY(hipMemcpyAsync(nb->xq.p + begin, src, (size_t)len * sizeof(float4), hipMemcpyHostToDevice, st)); }
         }
         if (nb->do_time) { HIP_TRY(hipEventRecord(nb->h2d_stop[iloc], st)); nb->h2d_timed[iloc] = true; }
         if (mark_x_written(nb, iloc)) { return 1; }
@@ -651,15 +704,30 @@ int cpyback_impl(nbnxn_hip *nb, float *h_f, int flags, int aloc)
     // with two streams the local copy-back waits for the non-local kernel, which also
     // writes local forces (nbnxn_cuda.cu:483-503)
     if (iloc == NBX_LOCAL && nb->two_streams) { HIP_TRY(hipStreamWaitEvent(st, nb->nonlocal_done, 0)); }
+    const bool   slots       = iloc == NBX_LOCAL && ener;
+    const size_t slots_bytes = NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float);
+    bool         slots_done  = false;
     if (len > 0 && h_f)
     {
-        HIP_TRY(hipMemcpyAsync(h_f + (size_t)begin * 3, nb->f.p + (size_t)begin * 3, (size_t)len * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        float       *dst   = h_f + (size_t)begin * 3;
+        const float *src   = nb->f.p + (size_t)begin * 3;
+        const size_t bytes = (size_t)len * 3 * sizeof(float);
+        void        *ddst  = (aligned16(dst) && aligned16(src) && bytes % 16 == 0) ? device_view_of_host(nb, dst) : nullptr;
+        if (ddst)
+        {
+            // forces and, with them, the partial-sum slots (h_stage is pinned and mapped by construction): one launch
+            void *dstage = slots ? nb->h_stage_dev : nullptr;   // (null if the mapping failed: the slots then go separately)
+            if (copy16(st, ddst, src, bytes, dstage, nb->out, dstage ? slots_bytes : 0)) { return 1; }
+            slots_done = dstage != nullptr;
+        }
+        else { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); }
     }
     // (one-stream handles run both localities in order on the same stream: nothing to signal)
     if (iloc == NBX_NONLOCAL && nb->two_streams) { HIP_TRY(hipEventRecord(nb->nonlocal_done, st)); }
-    if (iloc == NBX_LOCAL && ener)
+    if (slots && !slots_done)
     {
-        HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->out, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (nb->h_stage_dev && nb->copy_kernels) { if (copy16(st, nb->h_stage_dev, nb->out, slots_bytes)) { return 1; } }
+        else { HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->out, slots_bytes, hipMemcpyDeviceToHost, st)); }
     }
     if (nb->do_time) { HIP_TRY(hipEventRecord(nb->d2h_stop[iloc], st)); nb->d2h_timed[iloc] = true; }
     return 0;
@@ -672,7 +740,18 @@ int wait_impl(nbnxn_hip *nb, int flags, int aloc, float *e_lj, float *e_el, floa
     PList    &pl   = nb->plist[iloc];
     if (pl.nsci == 0) { return 0; }
     const bool ener = (flags & NBX_FORCE_VIRIAL) != 0;
-    HIP_TRY(hipStreamSynchronize(nb->stream[iloc]));
+    // The reference waits either in cudaStreamSynchronize or, with GMX_NO_CUDA_STREAMSYNC, by polling host memory for the
+    // end of the force copy (nbnxn_cuda.cu:607-624, nbnxn_cuda_data_mgmt.cu:618-705).  Here GMX_NO_HIP_STREAMSYNC polls the
+    // stream's state instead of a memory pattern: the host thread spins, and sees the end of the step a few microseconds
+    // before a blocked thread would be woken.
+    static const bool poll = getenv("GMX_NO_HIP_STREAMSYNC") != nullptr;
+    if (poll)
+    {
+        hipError_t q;
+        while ((q = hipStreamQuery(nb->stream[iloc])) == hipErrorNotReady) { }
+        HIP_TRY(q);
+    }
+    else { HIP_TRY(hipStreamSynchronize(nb->stream[iloc])); }
     if (nb->do_time)
     {
         nbx_wallclock_gpu_t &t = nb->timings;
@@ -753,6 +832,8 @@ void nbnxn_hip_pmalloc(void **h_ptr, size_t nbytes)
 {
     *h_ptr = nullptr;
     if (nbytes == 0) { return; }
+    // (coherent, non-coherent and write-combined pinned memory move xq / f at the same rates under the copy kernels:
+    // measured)
     if (hipHostMalloc(h_ptr, nbytes, hipHostMallocDefault) != hipSuccess)
     {
         *h_ptr = nullptr;
@@ -855,6 +936,8 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     HIP_TRY(hipMalloc((void **)&nb->shift_vec, NBX_SHIFTS * 3 * sizeof(float)));
     { bool re; if (reserve_f(nb, 0, &re)) { return 1; } }
     HIP_TRY(hipHostMalloc((void **)&nb->h_stage, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
+    if (hipHostGetDevicePointer(&nb->h_stage_dev, nb->h_stage, 0) != hipSuccess) { (void)hipGetLastError(); nb->h_stage_dev = nullptr; }
+    nb->copy_kernels = copy_kernels_default();
     memset(&nb->timings, 0, sizeof(nb->timings));
     if (clear_e_fshift(nb)) { return 1; }
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
@@ -1748,6 +1831,13 @@ int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune)
 {
     if (check_handle(nb) || check_loc(iloc)) { return 1; }
     nb->plist[iloc].do_prune = do_prune != 0;
+    return 0;
+}
+
+int nbnxn_hip_set_copy_kernels(nbnxn_hip_ptr_t nb, int on)
+{
+    if (check_handle(nb)) { return 1; }
+    nb->copy_kernels = on != 0;
     return 0;
 }
 

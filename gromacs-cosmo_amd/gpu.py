@@ -133,6 +133,7 @@ def load():
     lib.nbnxn_hip_get_output_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
     lib.nbnxn_hip_set_timing.argtypes = [vp, ci]
     lib.nbnxn_hip_set_clear_in_kernel.argtypes = [vp, ci]
+    lib.nbnxn_hip_set_copy_kernels.argtypes = [vp, ci]
     lib.nbnxn_hip_set_kernel_variant.argtypes = [vp, ci]
     # the host runtime raises instead of aborting the interpreter (gmx_fatal would abort)
     lib.nbnxn_hip_set_abort_on_error(0)
@@ -468,6 +469,10 @@ class NbnxnHip:
 
     def dd_finish(self):
         self._chk(self.lib.nbnxn_hip_dd_finish(self.h))
+
+    def set_copy_kernels(self, on):
+        """xq in / f and partial sums out by kernels on mapped host arrays (default) or by the copy engine"""
+        self._chk(self.lib.nbnxn_hip_set_copy_kernels(self.h, int(on)))
 
     def set_clear_in_kernel(self, on):
         self._chk(self.lib.nbnxn_hip_set_clear_in_kernel(self.h, int(on)))

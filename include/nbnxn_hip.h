@@ -694,6 +694,14 @@ int nbnxn_hip_set_prune(nbnxn_hip_ptr_t nb, int iloc, int do_prune);
  * clear_outputs while this is on: query them after it. */
 int nbnxn_hip_set_clear_in_kernel(nbnxn_hip_ptr_t nb, int on);
 
+/* Copy kernels (on by default; NBNXN_HIP_COPY_KERNELS=0 in the environment starts handles with them off).  The per-step
+ * moves of the reference's calling convention -- xq in at nbnxn_hip_launch_kernel (nbnxn_cuda.cu:347-348), f and the
+ * energy / shift-force partial sums out at nbnxn_hip_launch_cpyback (:492-522) -- are done by a kernel that reads /
+ * writes the caller's arrays directly when they are pinned and mapped into the device's address space (nbnxn_hip_pmalloc,
+ * hipHostMalloc, hipHostRegister) and 16-byte aligned; forces and partial sums then leave in ONE launch.  Pageable,
+ * unaligned or device-resident arrays go through hipMemcpyAsync as before.  Same bytes either way. */
+int nbnxn_hip_set_copy_kernels(nbnxn_hip_ptr_t nb, int on);
+
 /* switches the module's HIP-event timing (wallclock_gpu_t accounting) on or off; the default
  * follows the reference's bDoTime (nbnxn_cuda_data_mgmt.cu:714-715): on with one stream unless
  * GMX_DISABLE_HIP_TIMING is set, off with two.  Each timed launch carries two event records

@@ -50,6 +50,9 @@ void nbnxn_cuda_init(FILE *fplog, nbnxn_cuda_ptr_t *p_cu_nb, const gmx_gpu_info_
 {
     /* the device id nbnxn_cuda_init derives itself (nbnxn_cuda_data_mgmt.cu:566) */
     nbnxn_hip_init(fplog, (nbnxn_hip_ptr_t *)p_cu_nb, get_gpu_device_id(gpu_info, gpu_opt, my_gpu_index), bLocalAndNonlocal);
+    /* mdrun clears the outputs before every step (nbnxn_cuda_clear_outputs, sim_util.c:1547): with this switch the local
+     * launch of step n zeroes the buffer of step n + 1 and that call only flips buffers -- no fill between two steps */
+    if (*p_cu_nb && getenv("GMX_HIP_NB_NO_CLEAR_IN_KERNEL") == NULL) { nbnxn_hip_set_clear_in_kernel((nbnxn_hip_ptr_t)*p_cu_nb, 1); }
 }
 
 void nbnxn_cuda_init_const(nbnxn_cuda_ptr_t cu_nb, const interaction_const_t *ic, const nonbonded_verlet_group_t *nbv_group)

@@ -248,6 +248,77 @@ def test_clear_in_kernel_matches_fill(nb):
     assert relrms(f2, f_ref) < 2e-6 and abs(e2[1] - e_ref[1]) < 1e-6 * abs(e_ref[1])
 
 
+def test_copy_kernels_move_the_same_bytes_as_the_copy_engine(nb):
+    """nbnxn_hip_set_copy_kernels: the step of the reference's calling convention (host xq in at launch_kernel, f and the
+    partial sums out at launch_cpyback, wait_gpu) with pinned + mapped host arrays moved by kernels, against the same step
+    through hipMemcpyAsync: forces bit for bit, energies and shift forces equal (both fold the same slots in double) --
+    with the in-kernel clear on and off, with pageable arrays and with a pinned array that is not 16-byte aligned (both
+    fall back to the copy engine), and the coordinates really come from the host array of THAT step."""
+    import ctypes as C
+    p, ip, d = load_small("spce3240_ewald09")
+    _upload(nb, p, ip)
+    held = []
+
+    def pinned(nfloat):
+        ptr = C.c_void_p()
+        nb.lib.nbnxn_hip_pmalloc(C.byref(ptr), 4 * nfloat)
+        assert ptr.value
+        held.append(ptr)
+        return np.frombuffer((C.c_char * (4 * nfloat)).from_address(ptr.value), dtype=np.float32)
+
+    def step(xq, f):
+        e_lj, e_el, fsh = np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros((abi.SHIFTS, 3), np.float32)
+        f[:] = 7.0
+        nb.clear_outputs(abi.FORCE_VIRIAL)
+        nb.launch_kernel(xq, abi.FORCE_VIRIAL)
+        nb.launch_cpyback(f, abi.FORCE_VIRIAL)
+        nb.wait_gpu(abi.FORCE_VIRIAL, abi.LOCAL, e_lj, e_el, fsh)
+        return f.copy(), float(e_lj[0]), float(e_el[0]), fsh.copy()
+
+    n = p.natoms
+    xq_pin = pinned(4 * n).reshape(n, 4)
+    f_pin = pinned(3 * n).reshape(n, 3)
+    f_odd = pinned(3 * n + 4)[1:1 + 3 * n].reshape(n, 3)        # pinned, 4 bytes off a 16-byte boundary
+    xq_pag, f_pag = np.empty((n, 4), np.float32), np.empty((n, 3), np.float32)
+    rng = np.random.default_rng(5)
+    try:
+        for clear_in_kernel in (False, True):
+            nb.set_clear_in_kernel(clear_in_kernel)
+            for rep in range(2):
+                xq = p.xq.copy()
+                xq[:, :3] += rng.normal(0.0, 0.002, (n, 3)).astype(np.float32) * (rep > 0)     # a different x every step
+                xq_pin[:] = xq; xq_pag[:] = xq
+                nb.set_copy_kernels(False)
+                want = step(xq_pin, f_pin)
+                nb.set_copy_kernels(True)
+                for xq_h, f_h in ((xq_pin, f_pin), (xq_pag, f_pag), (xq_pin, f_odd), (xq_pag, f_pin)):
+                    got = step(xq_h, f_h)
+                    # the force atomics of a launch commute only up to rounding: launches of the same step differ in
+                    # the last bits, copies of ONE launch do not -- so compare at rounding level here ...
+                    assert relrms(got[0], want[0]) < 2e-6
+                    assert abs(got[1] - want[1]) < 1e-6 * abs(want[1]) and abs(got[2] - want[2]) < 1e-6 * abs(want[2])
+                    assert np.abs(got[3] - want[3]).max() < 1e-5 * np.abs(want[3]).max()
+                # ... and bit for bit on what one launch left in device memory: the kernel copy against the module's own
+                # device-to-host read of the same buffer
+                nb.clear_outputs(abi.FORCE_VIRIAL)
+                nb.launch_kernel(xq_pin, abi.FORCE_VIRIAL)
+                nb.launch_cpyback(f_pin, abi.FORCE_VIRIAL)
+                nb.wait_gpu(abi.FORCE_VIRIAL)
+                nb.set_copy_kernels(False)
+                nb.launch_cpyback(f_pag, abi.FORCE_VIRIAL)
+                nb.wait_gpu(0)
+                nb.set_copy_kernels(True)
+                assert np.array_equal(f_pin, f_pag)
+        f_ref, e_ref = nb.compute(xq, abi.FORCE_VIRIAL)
+        assert relrms(got[0], f_ref) < 2e-6 and abs(got[2] - e_ref[1]) < 1e-6 * abs(e_ref[1])
+    finally:
+        nb.set_clear_in_kernel(False)
+        nb.set_copy_kernels(True)
+        del xq_pin, f_pin, f_odd
+        for ptr in held:
+            nb.lib.nbnxn_hip_pfree(ptr)
+
+
 @pytest.mark.parametrize("model", ["spc", "spce"])
 def test_config4_size_properties(nb, model):
     """BASELINE config 4 size (13x13x14 tiles, 1,533,168 atoms, >1e9 pair slots) on one GPU.  The

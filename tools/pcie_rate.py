@@ -17,6 +17,7 @@ nb = g.gpu.NbnxnHip(0)
 p = g.workload.prepare(s, ip, nb.min_ci_balanced())
 g.workload.upload(nb, p, ip)
 fl = abi.FORCE_VIRIAL
+nb.set_clear_in_kernel(os.environ.get("PCIE_CLEAR_IN_KERNEL", "1") != "0")
 
 
 def pinned(shape, dtype=np.float32):
