@@ -1117,11 +1117,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
     {
         unsigned hwid;
         __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x]     = tl_t0;
         NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 1] = tl_t1;
         NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 2] = tl_t2;
         NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 4] = hwid | ((unsigned long long)(e.cj4_ind_end - e.cj4_ind_start) << 32);
+        NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 4] = hwid | ((unsigned long long)(e.cj4_ind_end - e.cj4_ind_start) << 32) | ((unsigned long long)(xcc & 0xf) << 56);
         NBX_TL_SYM[NBX_TL_WORDS * blockIdx.x + 5] = __builtin_amdgcn_s_memtime() - tl_c0;     // shader-clock cycles of the wave
     }
 #endif

@@ -30,7 +30,8 @@ fn = nb.lib.nbnxn_hip_debug_timeline if el == "ewald" else nb.lib.nbnxn_hip_debu
 fn.argtypes = [C.c_void_p, C.c_int]
 assert fn(tl.ctypes.data_as(C.c_void_p), n) == 0
 t = tl[:, :4].astype(np.int64)
-ncj4 = (tl[:, 4] >> np.uint64(32)).astype(np.int64)
+ncj4 = ((tl[:, 4] >> np.uint64(32)) & np.uint64(0xffffff)).astype(np.int64)
+xcc = (tl[:, 4] >> np.uint64(56)).astype(np.int64)
 hw = (tl[:, 4] & np.uint64(0xffffffff)).astype(np.int64)
 base = t[:, 0].min()
 t = (t - base) * 0.01      # us
@@ -62,6 +63,23 @@ for a, b in zip(edges[:-1], edges[1:]):
 last = np.sort(t3)[::-1]
 print("last waves end at", np.round(last[:5], 1), " 99%/95%/90% of waves ended by", np.round(np.percentile(t3, [99, 95, 90]), 1))
 print("first wave of the final 10% starts at", np.round(np.sort(t0)[int(0.9 * n)], 1))
+
+# the tail: which waves are still running at the end, and how evenly the SIMDs finish (a SIMD = XCC id + HW_ID without its
+# wave-slot bits [3:0])
+simd = xcc * (1 << 20) + (hw >> 4)
+ids = np.unique(simd)
+last_end = np.array([t3[simd == s].max() for s in ids])
+busy = np.array([dur[simd == s].sum() for s in ids])
+print(f"{len(ids)} SIMDs seen; a SIMD's last wave ends at: min {last_end.min():.1f}  5% {np.percentile(last_end, 5):.1f}  median {np.median(last_end):.1f}"
+      f"  95% {np.percentile(last_end, 95):.1f}  max {last_end.max():.1f} us;  sum of wave times per SIMD: min {busy.min():.0f} median {np.median(busy):.0f} max {busy.max():.0f} us")
+for frac in (0.85, 0.9, 0.95):
+    m = t3 > frac * span
+    print(f"  waves ending after {frac * span:5.1f} us: {int(m.sum()):5d}; groups per entry {ncj4[m].mean():.2f}; started: median {np.median(t0[m]):.1f}, earliest {t0[m].min():.1f} us;"
+          f" of them started in the first 2 us: {int((t0[m] < 2).sum())}; duration median {np.median(dur[m]):.1f} us")
+for a, b in ((0.0, 2.0), (2.0, 0.5 * span), (0.5 * span, 0.8 * span), (0.8 * span, span)):
+    m = (t0 >= a) & (t0 < b)
+    if m.sum():
+        print(f"  entries started in [{a:5.1f}, {b:5.1f}) us: {int(m.sum()):5d}, groups {ncj4[m].mean():.2f}, end: median {np.median(t3[m]):.1f}  95% {np.percentile(t3[m], 95):.1f}  max {t3[m].max():.1f} us")
 
 # where the time per unit of work goes over the launch: entries binned by their start time; work = live cluster pairs
 # (set bits of the pruned interaction masks) and j-clusters with at least one live pair

@@ -82,6 +82,12 @@ __global__ void __launch_bounds__(64) k(float *out, int iters, unsigned long lon
             if (KIND == 61) { I_FMA3(a0) I_SALU I_SALU I_FMA3(a1) I_SALU I_SALU I_FMA3(a2) I_SALU I_SALU I_FMA3(a3) I_SALU I_SALU I_FMA3(a4) I_SALU I_SALU I_FMA3(a5) I_SALU I_SALU I_FMA3(a6) I_SALU I_SALU I_FMA3(a7) I_SALU I_SALU }
             if (KIND == 62) { I_FMA3(a0) I_FMA3(a1) I_BRNT I_FMA3(a2) I_FMA3(a3) I_BRNT I_FMA3(a4) I_FMA3(a5) I_BRNT I_FMA3(a6) I_FMA3(a7) I_BRNT }
             if (KIND == 63) { I_FMA3(a0) I_FMA3(a1) I_BRT(a0) I_FMA3(a2) I_FMA3(a3) I_BRT(a2) I_FMA3(a4) I_FMA3(a5) I_BRT(a4) I_FMA3(a6) I_FMA3(a7) I_BRT(a6) }
+            // dependent chains: 8 instructions on 1 / 2 / 4 registers (what a lone wave's pair body looks like)
+            if (KIND == 70) { I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) }
+            if (KIND == 71) { I_FMA3(a0) I_FMA3(a1) I_FMA3(a0) I_FMA3(a1) I_FMA3(a0) I_FMA3(a1) I_FMA3(a0) I_FMA3(a1) }
+            if (KIND == 72) { I_FMA3(a0) I_FMA3(a1) I_FMA3(a2) I_FMA3(a3) I_FMA3(a0) I_FMA3(a1) I_FMA3(a2) I_FMA3(a3) }
+            if (KIND == 73) { I_RCP(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) I_RCP(a0) I_FMA3(a0) I_FMA3(a0) I_FMA3(a0) }
+            if (KIND == 74) { I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU I_FMA3(a0) I_SALU }
             if (KIND == 25) { REP8(I_BFI) }
             if (KIND == 26) { REP8(I_BFIS) }
             if (KIND == 27) { REP8(I_FMA1) }
@@ -144,7 +150,7 @@ void run(const char *name)
     float *out; unsigned long long *clk, h[2];
     hipMalloc(&out, 64 * 65536 * sizeof(float)); hipMalloc(&clk, 16);
     const int iters = 2000;
-    for (int wps : {1, 4})
+    for (int wps : {1, 2, 4, 5})
     {
         const int nblk = 256 * 4 * wps;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -165,6 +171,7 @@ void run(const char *name)
 
 int main(int argc, char **)
 {
+    if (argc > 2) { run<21>("8 independent fma"); run<70>("8 fma, one chain"); run<71>("8 fma, two chains"); run<72>("8 fma, four chains"); run<73>("2 rcp + 6 fma, one chain"); run<74>("8 fma one chain + 8 salu"); run<60>("8 fma indep + 8 salu"); return 0; }
     if (argc > 1) { run<60>("8 fma + 8 salu"); run<61>("8 fma + 16 salu"); run<62>("8 fma + 4 (cmp+branch not taken)"); run<63>("8 fma + 4 (cmp + taken branch over a mov)"); run<21>("fma 3 vgpr"); run<50>("1 rcp + 7 fma"); run<51>("2 rcp + 6 fma"); run<52>("2 (cmp+cnd) + 6 fma"); run<53>("2 dpp + 6 fma"); run<54>("2 fma-sgpr + 6 fma"); return 0; }
     run<0>("v_fma_f32"); run<1>("v_fmac_f32"); run<2>("v_mul_f32"); run<3>("v_sub_f32"); run<4>("v_add_f32");
     run<5>("v_mov_b32"); run<6>("v_and_b32"); run<7>("v_cndmask"); run<8>("v_cmp vcc"); run<9>("v_cmp sgpr");
