@@ -4,6 +4,7 @@
 // GROMACS 5.0.4's nbnxn gridding and list construction (src/gromacs/mdlib/nbnxn_search.c,
 // nbnxn_atomdata.c), cited per function below, not its code structure.
 #include "nbnxn_host.h"
+#include "nbnxn_list_rules.h"
 
 #include <algorithm>
 #include <cmath>
@@ -940,13 +941,26 @@ int nbnxn_host_make_pairlist_zones(nbnxn_host_ptr_t h, int iloc, int nzp, const 
         L.nci_tot += pl.nci_tot;
     }
 
-    // sort_sci (:5517-5580): descending cj4 count, stable, counts clipped at twice the mean
+    // sort_sci (:5517-5580): descending cj4 count, stable, counts clipped at twice the mean.  Second key (not in the
+    // reference, nbx_sci_pair_key): among entries of one group count the ones with more cluster pairs come first, so that
+    // what the GPU starts last is the lightest work of the smallest size class.
     if (L.cj4.size() > L.sci.size() && !L.sci.empty())
     {
         const int m = (int)(2 * L.cj4.size() / L.sci.size());
-        std::stable_sort(L.sci.begin(), L.sci.end(), [m](const nbx_sci_t &a, const nbx_sci_t &b) {
-            return std::min(m, a.cj4_ind_end - a.cj4_ind_start) > std::min(m, b.cj4_ind_end - b.cj4_ind_start);
-        });
+        std::vector<std::pair<int, nbx_sci_t>> keyed(L.sci.size());
+        for (size_t i = 0; i < L.sci.size(); i++)
+        {
+            const nbx_sci_t &e = L.sci[i];
+            int npair = 0;
+            for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++) { npair += __builtin_popcount(L.cj4[j4].imei[0].imask | L.cj4[j4].imei[1].imask); }
+            const int k1 = m - std::min(m, e.cj4_ind_end - e.cj4_ind_start);
+            // (only for lists that were split for the GPU's balance, with the progressive classes on: a list that was
+            // not split keeps the reference's order exactly)
+            const int k2 = (nsp_max > 0 && h->progressive) ? nbx_sci_pair_key(e.cj4_ind_end - e.cj4_ind_start, npair, m) : 0;
+            keyed[i] = {k1 * NBX_SCI_PAIR_KEYS + k2, e};
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, nbx_sci_t> &a, const std::pair<int, nbx_sci_t> &b) { return a.first < b.first; });
+        for (size_t i = 0; i < L.sci.size(); i++) { L.sci[i] = keyed[i].second; }
     }
 
     nbx_pairlist_t &v = L.view;

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "nbnxn_search.h"
+#include "nbnxn_list_rules.h"
 
 namespace {
 
@@ -893,18 +894,28 @@ __global__ void k_split(int nentries, EntryMap em, const int *__restrict__ ncj, 
 // (five merge passes) by two short kernels and a scan.
 __device__ __forceinline__ int sci_sort_key(const nbx_sci_t &e, int m) { return m - min(m, e.cj4_ind_end - e.cj4_ind_start); }
 
-// the same key for the library sort that takes over when m + 1 > 64
-__global__ void k_sort_keys(int nsci, const nbx_sci_t *__restrict__ sci, int m, unsigned *__restrict__ key)
+// second key (nbnxn_list_rules.h): the entry's cluster pairs in NBX_SCI_PAIR_KEYS buckets, most pairs first
+__device__ __forceinline__ int sci_pair_key(const nbx_sci_t &e, const nbx_cj4_t *__restrict__ cj4, int m)
+{
+    int npair = 0;
+    for (int j4 = e.cj4_ind_start; j4 < e.cj4_ind_end; j4++) { npair += __popc(cj4[j4].imei[0].imask | cj4[j4].imei[1].imask); }
+    return nbx_sci_pair_key(e.cj4_ind_end - e.cj4_ind_start, npair, m);
+}
+
+// both keys in one for the library sort that takes over when m + 1 > 64
+__global__ void k_sort_keys(int nsci, const nbx_sci_t *__restrict__ sci, const nbx_cj4_t *__restrict__ cj4, int m, int pair_key, unsigned *__restrict__ key)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsci) { return; }
-    key[i] = (unsigned)sci_sort_key(sci[i], m);
+    key[i] = (unsigned)sci_sort_key(sci[i], m) * NBX_SCI_PAIR_KEYS + (pair_key ? (unsigned)sci_pair_key(sci[i], cj4, m) : 0u);
 }
 
-template <bool COUNT>
+// PAIRS: the pass on the second key (run FIRST: two stable passes, least significant key first, give the order by
+// (group count, pair key)); kmax = the largest key of the pass (m, or NBX_SCI_PAIR_KEYS - 1)
+template <bool COUNT, bool PAIRS>
 __global__ void __launch_bounds__(64)
-k_sort_sci(int nsci, int nwaves, int m, const nbx_sci_t *__restrict__ sci, int *__restrict__ hist, const int *__restrict__ first,
-           nbx_sci_t *__restrict__ sci_out)
+k_sort_sci(int nsci, int nwaves, int m, int kmax, const nbx_sci_t *__restrict__ sci, const nbx_cj4_t *__restrict__ cj4, int *__restrict__ hist,
+           const int *__restrict__ first, nbx_sci_t *__restrict__ sci_out)
 {
     const int  w    = blockIdx.x;
     const int  lane = threadIdx.x;
@@ -912,22 +923,22 @@ k_sort_sci(int nsci, int nwaves, int m, const nbx_sci_t *__restrict__ sci, int *
     const bool have = i < nsci;
     nbx_sci_t  e;
     if (have) { e = sci[i]; }
-    const int key = have ? sci_sort_key(e, m) : -1;
+    const int key = have ? (PAIRS ? sci_pair_key(e, cj4, m) : sci_sort_key(e, m)) : -1;
     if (COUNT)
     {
         // lane k counts key k
         int mine = 0;
-        for (int k = 0; k <= m; k++)
+        for (int k = 0; k <= kmax; k++)
         {
             const unsigned long long b = __ballot(key == k);
             if (lane == k) { mine = __popcll(b); }
         }
-        if (lane <= m) { hist[(size_t)lane * nwaves + w] = mine; }
+        if (lane <= kmax) { hist[(size_t)lane * nwaves + w] = mine; }
     }
     else
     {
         unsigned long long same = 0;
-        for (int k = 0; k <= m; k++)
+        for (int k = 0; k <= kmax; k++)
         {
             const unsigned long long b = __ballot(key == k);
             if (key == k) { same = b; }
@@ -1368,28 +1379,45 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, int nzp, c
     if (ncj4 > nsci && nsci > 0)
     {
         const int m = (int)(2 * (size_t)ncj4 / (size_t)nsci);
+        // second key (nbnxn_list_rules.h): only for lists that were split for the GPU's balance with the progressive classes
+        const bool pair_key = nsp_max > 0 && s->progressive;
         if (m + 1 <= 64)
         {
             const int    nwaves = (nsci + 63) / 64;
-            const size_t nh     = (size_t)(m + 1) * nwaves;
-            if (s->sort_hist.reserve(nh + 1) || s->sort_first.reserve(nh + 1)) { return 1; }
-            hipLaunchKernelGGL((k_sort_sci<true>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, s->sci_a.p, s->sort_hist.p, (const int *)nullptr,
-                               (nbx_sci_t *)nullptr);
+            const size_t nh2    = (size_t)NBX_SCI_PAIR_KEYS * nwaves, nh = (size_t)(m + 1) * nwaves;
+            if (s->sort_hist.reserve(nh2 + 1) || s->sort_first.reserve(nh2 + 1)) { return 1; }
+            // the pair key first (sci_a -> sci_b), then the group count (sci_b -> sci_a): both passes are stable
+            const nbx_sci_t *src = s->sci_a.p;
+            nbx_sci_t       *dst = s->sci_b.p;
+            if (pair_key)
+            {
+                hipLaunchKernelGGL((k_sort_sci<true, true>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, NBX_SCI_PAIR_KEYS - 1, src, s->cj4.p,
+                                   s->sort_hist.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
+                S_TRY(hipGetLastError());
+                S_TRY(nbx_prim_exclusive_sum(s->tmp, s->sort_hist.p, s->sort_first.p, (int)nh2, st));
+                hipLaunchKernelGGL((k_sort_sci<false, true>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, NBX_SCI_PAIR_KEYS - 1, src, s->cj4.p,
+                                   (int *)nullptr, s->sort_first.p, dst);
+                S_TRY(hipGetLastError());
+                src = s->sci_b.p; dst = s->sci_a.p;
+            }
+            hipLaunchKernelGGL((k_sort_sci<true, false>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, m, src, s->cj4.p, s->sort_hist.p,
+                               (const int *)nullptr, (nbx_sci_t *)nullptr);
             S_TRY(hipGetLastError());
             S_TRY(nbx_prim_exclusive_sum(s->tmp, s->sort_hist.p, s->sort_first.p, (int)nh, st));
-            hipLaunchKernelGGL((k_sort_sci<false>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, s->sci_a.p, (int *)nullptr, s->sort_first.p,
-                               s->sci_b.p);
+            hipLaunchKernelGGL((k_sort_sci<false, false>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, m, src, s->cj4.p, (int *)nullptr,
+                               s->sort_first.p, dst);
             S_TRY(hipGetLastError());
+            sci_final = dst;
         }
         else
         {
             int bits = 1;
-            while ((1 << bits) <= m) { bits++; }
-            hipLaunchKernelGGL(k_sort_keys, dim3(blocks_for(nsci, 256)), dim3(256), 0, st, nsci, s->sci_a.p, m, s->skey_in.p);
+            while ((1 << bits) <= (m + 1) * NBX_SCI_PAIR_KEYS) { bits++; }
+            hipLaunchKernelGGL(k_sort_keys, dim3(blocks_for(nsci, 256)), dim3(256), 0, st, nsci, s->sci_a.p, s->cj4.p, m, pair_key ? 1 : 0, s->skey_in.p);
             S_TRY(hipGetLastError());
             S_TRY(nbx_prim_sort_u32_sci(s->tmp, s->skey_in.p, s->skey_out.p, s->sci_a.p, s->sci_b.p, nsci, bits, st));
+            sci_final = s->sci_b.p;
         }
-        sci_final = s->sci_b.p;
     }
     out->nsci = nsci; out->ncj4 = ncj4; out->nexcl = nexcl; out->nci_tot = nci_tot;
     out->sci = sci_final; out->cj4 = s->cj4.p; out->excl = s->excl.p;

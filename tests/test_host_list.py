@@ -233,3 +233,45 @@ def test_put_atoms_in_box_triclinic():
     assert np.array_equal(g.system.put_atoms_in_box(y, box), y)
     r = g.system.put_atoms_in_box(x, np.diag(box))
     assert (r >= 0).all() and (r < np.diag(box)).all() and np.abs(r - np.mod(x, np.diag(box))).max() < 1e-5
+
+
+def test_second_sort_key_orders_small_entries_by_their_cluster_pairs():
+    """nbnxn_list_rules.h: a list that was split for the GPU is sorted by (group count clipped at m, pair key), stable;
+    the pair key only differs from a constant for entries of at most 2 m / 3 groups and is the entry's cluster-pair count
+    in 64 buckets, most pairs first.  A list that was not split keeps the reference's sort_sci order (one key); with the
+    progressive classes off the second key is off too; the entries themselves are the same set either way."""
+    s = g.system.water_box(3, 3, 3, model="spce")
+    ip = g.system.ewald(0.9)
+    pop = np.array([bin(i).count("1") for i in range(256)])
+
+    def keys(pl):
+        im = (pl.cj4["imei"]["imask"][:, 0] | pl.cj4["imei"]["imask"][:, 1]).astype(np.uint32)
+        per = pop[im & 0xff] + pop[(im >> 8) & 0xff] + pop[(im >> 16) & 0xff] + pop[im >> 24]
+        cs = np.concatenate([[0], np.cumsum(per)])
+        ng = (pl.sci["cj4_ind_end"] - pl.sci["cj4_ind_start"]).astype(np.int64)
+        npair = cs[pl.sci["cj4_ind_end"].astype(np.int64)] - cs[pl.sci["cj4_ind_start"].astype(np.int64)]
+        m = 2 * pl.ncj4 // pl.nsci
+        lim = 2 * m // 3
+        k2 = np.where(ng <= lim, 63 - np.minimum(63, npair // max(1, (lim + 1) // 2)), 63)
+        return m - np.minimum(ng, m), k2, ng
+
+    p = g.workload.prepare(s, ip, 4000)                         # split: both keys
+    k1, k2, ng = keys(p.pl)
+    assert p.pl.nsci > 2000 and len(np.unique(k2)) > 8
+    comp = k1 * 64 + k2
+    assert (np.diff(comp) >= 0).all()
+    _check_list_invariants(p)
+    # the same entries as without the second key, and that list is NOT ordered by it
+    h = g.host.NbnxnHost(s.box)
+    h.put_on_grid(0, (0.0, 0.0, 0.0), s.box_diag, 0, s.x)
+    xq, _ = h.set_atomdata(s.ntype + 1, s.type, s.q)
+    h.copy_x_to_xq(s.x, xq)
+    h.set_progressive_balance(False)
+    pl0 = h.make_pairlist(abi.LOCAL, ip.rlist, xq, s.excl_index, s.excl_a, 4000)
+    k1, k2, _ = keys(pl0)
+    assert (np.diff(k1) >= 0).all() and not (np.diff(k1 * 64 + k2) >= 0).all()
+    # not split: one key, whatever the pair counts
+    p1 = g.workload.prepare(s, ip, 0)
+    k1, k2, _ = keys(p1.pl)
+    assert (np.diff(k1) >= 0).all()
+    assert not (np.diff(k1 * 64 + k2) >= 0).all()
