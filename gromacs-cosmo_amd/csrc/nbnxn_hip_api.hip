@@ -212,6 +212,9 @@ struct nbnxn_hip {
     float *h_stage = nullptr;   // host copy of `out`, folded in double by fold_outputs()
     void  *h_stage_dev = nullptr;   // the device's view of h_stage (pinned + mapped), for the copy kernels
     bool   copy_kernels = true;     // nbnxn_hip_set_copy_kernels
+    double *h_fold = nullptr;       // pinned + mapped: the slots summed by the copy-back kernel, {e_lj, e_el, fshift[45][3]}
+    void   *h_fold_dev = nullptr;
+    bool    slots_folded = false;   // the last local copy-back left its sums in h_fold (else: raw slots in h_stage)
     // domain decomposition over RCCL (nbnxn_hip_dd_*): one pulse along one dimension
     ncclComm_t    dd_comm = nullptr;
     int           dd_rank = -1, dd_nranks = 0;
@@ -604,6 +607,30 @@ __global__ void __launch_bounds__(256) nbx_copy16_kernel(nbx_copy_f32x4 *__restr
     else if (i - n0 < n1) { __builtin_nontemporal_store(__builtin_nontemporal_load(&src1[i - n0]), &dst1[i - n0]); }
 }
 
+// launch_cpyback's kernel: blocks [0, ncopy) move the forces to the caller's mapped array; one more block folds the
+// partial-sum slots in double, in slot order -- bit for bit what fold_outputs() does on the host -- and writes the 137
+// sums to the mapped staging words: the host then reads 1.1 KB instead of summing 36 KB that the device has just
+// written (every line of them a miss in the host's caches, ~6 us per step)
+__global__ void __launch_bounds__(256) nbx_cpyback_kernel(nbx_copy_f32x4 *__restrict__ dst, const nbx_copy_f32x4 *__restrict__ src, const int n,
+                                                          const float *__restrict__ slots, double *__restrict__ folded, const int ncopy)
+{
+    if ((int)blockIdx.x < ncopy)
+    {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n) { __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]); }
+    }
+    else
+    {
+        const int k = threadIdx.x;
+        if (k < 2 + NBX_SHIFTS * 3)
+        {
+            double sum = 0;
+            for (int s = 0; s < NBX_OUT_SLOTS; s++) { sum += (double)slots[s * NBX_OUT_STRIDE + k]; }
+            folded[k] = sum;
+        }
+    }
+}
+
 bool copy_kernels_default()
 {
     static const bool on = !(getenv("NBNXN_HIP_COPY_KERNELS") && atoi(getenv("NBNXN_HIP_COPY_KERNELS")) == 0);
@@ -713,19 +740,24 @@ int cpyback_impl(nbnxn_hip *nb, float *h_f, int flags, int aloc)
         const float *src   = nb->f.p + (size_t)begin * 3;
         const size_t bytes = (size_t)len * 3 * sizeof(float);
         void        *ddst  = (aligned16(dst) && aligned16(src) && bytes % 16 == 0) ? device_view_of_host(nb, dst) : nullptr;
-        if (ddst)
+        if (ddst && slots && nb->h_fold_dev)
         {
-            // forces and, with them, the partial-sum slots (h_stage is pinned and mapped by construction): one launch
-            void *dstage = slots ? nb->h_stage_dev : nullptr;   // (null if the mapping failed: the slots then go separately)
-            if (copy16(st, ddst, src, bytes, dstage, nb->out, dstage ? slots_bytes : 0)) { return 1; }
-            slots_done = dstage != nullptr;
+            // forces and, with them, the folded partial sums (h_fold is pinned and mapped by construction): one launch
+            const int n = (int)(bytes / 16), ncopy = (n + 255) / 256;
+            hipLaunchKernelGGL(nbx_cpyback_kernel, dim3(ncopy + 1), dim3(256), 0, st, (nbx_copy_f32x4 *)ddst, (const nbx_copy_f32x4 *)src, n,
+                               (const float *)nb->out, (double *)nb->h_fold_dev, ncopy);
+            HIP_TRY(hipGetLastError());
+            slots_done = true;
+            nb->slots_folded = true;
         }
+        else if (ddst) { if (copy16(st, ddst, src, bytes)) { return 1; } }
         else { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); }
     }
     // (one-stream handles run both localities in order on the same stream: nothing to signal)
     if (iloc == NBX_NONLOCAL && nb->two_streams) { HIP_TRY(hipEventRecord(nb->nonlocal_done, st)); }
     if (slots && !slots_done)
     {
+        nb->slots_folded = false;
         if (nb->h_stage_dev && nb->copy_kernels) { if (copy16(st, nb->h_stage_dev, nb->out, slots_bytes)) { return 1; } }
         else { HIP_TRY(hipMemcpyAsync(nb->h_stage, nb->out, slots_bytes, hipMemcpyDeviceToHost, st)); }
     }
@@ -765,7 +797,8 @@ int wait_impl(nbnxn_hip *nb, int flags, int aloc, float *e_lj, float *e_el, floa
     if (iloc == NBX_LOCAL && ener)
     {
         double e[2 + NBX_SHIFTS * 3];
-        fold_outputs(nb, e);
+        if (nb->slots_folded) { memcpy(e, nb->h_fold, sizeof(e)); }   // the copy-back kernel summed the slots
+        else { fold_outputs(nb, e); }
         if (e_lj) { *e_lj += (float)e[0]; }
         if (e_el) { *e_el += (float)e[1]; }
         if (fshift)
@@ -938,6 +971,8 @@ int nbnxn_hip_init(FILE *fplog, nbnxn_hip_ptr_t *p_nb, int device_id, int bLocal
     HIP_TRY(hipHostMalloc((void **)&nb->h_stage, NBX_OUT_SLOTS * NBX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
     if (hipHostGetDevicePointer(&nb->h_stage_dev, nb->h_stage, 0) != hipSuccess) { (void)hipGetLastError(); nb->h_stage_dev = nullptr; }
     nb->copy_kernels = copy_kernels_default();
+    HIP_TRY(hipHostMalloc((void **)&nb->h_fold, (2 + NBX_SHIFTS * 3) * sizeof(double), hipHostMallocDefault));
+    if (hipHostGetDevicePointer(&nb->h_fold_dev, nb->h_fold, 0) != hipSuccess) { (void)hipGetLastError(); nb->h_fold_dev = nullptr; }
     memset(&nb->timings, 0, sizeof(nb->timings));
     if (clear_e_fshift(nb)) { return 1; }
     HIP_TRY(hipStreamSynchronize(nb->stream[0]));
@@ -1160,6 +1195,7 @@ int nbnxn_hip_free(nbnxn_hip_ptr_t nb)
     }
     (void)hipFree(nb->shift_vec);
     (void)hipHostFree(nb->h_stage);
+    if (nb->h_fold) { (void)hipHostFree(nb->h_fold); }
     dev_free(nb->d_a); dev_free(nb->d_cell); dev_free(nb->d_x); dev_free(nb->d_fa);
     dev_free(nb->c6grid); dev_free(nb->coulomb_tab);
     dev_free(nb->d_type_in); dev_free(nb->d_excl_index); dev_free(nb->d_excl_a); dev_free(nb->d_q_in);

@@ -698,7 +698,8 @@ int nbnxn_hip_set_clear_in_kernel(nbnxn_hip_ptr_t nb, int on);
  * moves of the reference's calling convention -- xq in at nbnxn_hip_launch_kernel (nbnxn_cuda.cu:347-348), f and the
  * energy / shift-force partial sums out at nbnxn_hip_launch_cpyback (:492-522) -- are done by a kernel that reads /
  * writes the caller's arrays directly when they are pinned and mapped into the device's address space (nbnxn_hip_pmalloc,
- * hipHostMalloc, hipHostRegister) and 16-byte aligned; forces and partial sums then leave in ONE launch.  Pageable,
+ * hipHostMalloc, hipHostRegister) and 16-byte aligned; the forces then leave in ONE launch that also sums the partial-sum
+ * slots (in double, in slot order: the bits the host-side sum gives) so that the host reads 137 numbers.  Pageable,
  * unaligned or device-resident arrays go through hipMemcpyAsync as before.  Same bytes either way. */
 int nbnxn_hip_set_copy_kernels(nbnxn_hip_ptr_t nb, int on);
 
