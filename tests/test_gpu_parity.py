@@ -300,15 +300,19 @@ def test_copy_kernels_move_the_same_bytes_as_the_copy_engine(nb):
                     assert np.abs(got[3] - want[3]).max() < 1e-5 * np.abs(want[3]).max()
                 # ... and bit for bit on what one launch left in device memory: the kernel copy against the module's own
                 # device-to-host read of the same buffer
+                # (and the sums of the partial-sum slots made by the copy-back kernel against the host's sums of the same slots)
+                ea, eb = [np.zeros(1, np.float32) for _ in range(2)], [np.zeros(1, np.float32) for _ in range(2)]
+                fa, fb = np.zeros((abi.SHIFTS, 3), np.float32), np.zeros((abi.SHIFTS, 3), np.float32)
                 nb.clear_outputs(abi.FORCE_VIRIAL)
                 nb.launch_kernel(xq_pin, abi.FORCE_VIRIAL)
                 nb.launch_cpyback(f_pin, abi.FORCE_VIRIAL)
-                nb.wait_gpu(abi.FORCE_VIRIAL)
+                nb.wait_gpu(abi.FORCE_VIRIAL, abi.LOCAL, ea[0], ea[1], fa)
                 nb.set_copy_kernels(False)
                 nb.launch_cpyback(f_pag, abi.FORCE_VIRIAL)
-                nb.wait_gpu(0)
+                nb.wait_gpu(abi.FORCE_VIRIAL, abi.LOCAL, eb[0], eb[1], fb)
                 nb.set_copy_kernels(True)
                 assert np.array_equal(f_pin, f_pag)
+                assert ea[0][0] == eb[0][0] and ea[1][0] == eb[1][0] and np.array_equal(fa, fb) and ea[1][0] != 0.0
         f_ref, e_ref = nb.compute(xq, abi.FORCE_VIRIAL)
         assert relrms(got[0], f_ref) < 2e-6 and abs(got[2] - e_ref[1]) < 1e-6 * abs(e_ref[1])
     finally:
