@@ -73,7 +73,7 @@ __device__ __forceinline__ nbx_f32x4 lds_load_f32x4_volatile(const float4 *p)
 #define NBX_FJ_CAP 32
 #endif
 #ifndef NBX_CPAIR
-#define NBX_CPAIR 0
+#define NBX_CPAIR 2      // the LJ entry of a pair read from the LDS table when the pair is computed: 0 never, 1 always, 2 Ewald flavours
 #endif
 #ifndef NBX_JRED2
 #define NBX_JRED2 1
@@ -94,7 +94,15 @@ __device__ __forceinline__ nbx_f32x4 lds_load_f32x4_volatile(const float4 *p)
 #define NBX_KERNEL_WAVES_EW 5    // waves per SIMD the flavours with their i-atoms in LDS are compiled for (5 needs <= 96 registers)
 #endif
 constexpr bool xi_in_lds(int el) { return NBX_XI_LDS == 1 || (NBX_XI_LDS == 2 && el != NBX_EL_RF); }
-constexpr bool xi_prefetch(int el, bool ener) { return xi_in_lds(el) && (NBX_XI_PREFETCH == 1 || (NBX_XI_PREFETCH == 2 && (el == NBX_EL_RF || !ener))); }
+// Per-pair LJ entries (lj_per_pair): instead of the eight entries of a j-cluster fetched ahead into 16 registers, each
+// pair reads its own 8-byte entry when it is computed: 14 registers fewer.  Measured (profiles/r3_r_cpair_ab.txt): Ewald F
+// -2.5 %, Ewald V+F -1.2 % (with the i-atom prefetch, which the freed registers make pay there too), RF F +4.6 %: so
+// for the Ewald flavours only, and never with the LJ-PME grid column (16-byte entries).
+constexpr bool lj_per_pair(int el, int vmod, bool lds_table) { return lds_table && vmod != 3 && (NBX_CPAIR == 1 || (NBX_CPAIR == 2 && el != NBX_EL_RF)); }
+constexpr bool xi_prefetch(int el, bool ener, bool per_pair_lj)
+{
+    return xi_in_lds(el) && (NBX_XI_PREFETCH == 1 || (NBX_XI_PREFETCH == 2 && (el == NBX_EL_RF || !ener || per_pair_lj)));
+}
 // (the global-table instantiations, more than 16 atom types, keep 4 waves: at 96 registers some of them spill)
 constexpr int  kernel_waves(int el, bool ener, bool lds_table)
 {
@@ -620,7 +628,9 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     }
     else
 #endif
-    if (NBFP_LDS && NBX_CPAIR && !THIRD) { }
+    constexpr bool CPAIR = lj_per_pair(EL, VMOD, NBFP_LDS);
+    constexpr bool XIPF  = xi_prefetch(EL, ENER, CPAIR);
+    if (CPAIR) { }
     else if (NBFP_LDS)
     {
         const char *row = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
@@ -657,16 +667,14 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
             if (EL != NBX_EL_RF) { c[i].x *= a.k.c6scale; c[i].y *= a.k.c12scale; cg[i] *= a.k.c6scale; }
         }
     }
-#if NBX_CPAIR
-    // experiment: the LJ entry of a pair is read when the pair is computed (2 live registers instead of 16)
+    // lj_per_pair: the LJ entry of a pair is read when the pair is computed (2 live registers instead of 16)
     const char *crow = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
-#endif
     // i-atoms from LDS (xi_in_lds), xi_prefetch: the row of pair i + 1 is requested at the head of pair i, outside the test of pair
     // i + 1's mask bit -- as a volatile access, which the compiler neither sinks into the conditional body (where its
     // whole latency stood between the branch and the first subtraction) nor splits into a 12- and a 4-byte read (8 + 2
     // LDS cycles where the 16-byte read takes 4, MI355X_MICROARCH.md)
     nbx_f32x4 xin;
-    if (xi_prefetch(EL, ENER)) { xin = lds_load_f32x4_volatile(s_xi_lane); }
+    if (XIPF) { xin = lds_load_f32x4_volatile(s_xi_lane); }
     float4 xj = s.x;
     // Ewald: scaled coordinates relative to the entry's origin, see the kernel
     if (EL != NBX_EL_RF) { xj.x = fmaf(xj.x, a.k.xscale, ox); xj.y = fmaf(xj.y, a.k.xscale, oy); xj.z = fmaf(xj.z, a.k.xscale, oz); }
@@ -676,7 +684,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
     {
         const unsigned bit = 1u << (JM * 8 + i);
         float4 xiv = xi[i];
-        if (xi_prefetch(EL, ENER))
+        if (XIPF)
         {
             xiv = make_float4(xin.x, xin.y, xin.z, xin.w);
             if (i < 7) { xin = lds_load_f32x4_volatile(s_xi_lane + (i + 1) * 8); }
@@ -685,11 +693,9 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = !PLAIN && central && (cj == sci * 8 + i);
             bool       any  = true;
-#if NBX_CPAIR
-            if (NBFP_LDS && !THIRD) { c[i] = *reinterpret_cast<const float2 *>(crow + 8 * i); cg[i] = 0.0f; }
-#endif
+            if (CPAIR) { c[i] = *reinterpret_cast<const float2 *>(crow + 8 * i); cg[i] = 0.0f; }
             // Ewald flavours: the i-atoms stay in LDS and are read per pair (xi_in_lds)
-            if (xi_in_lds(EL) && !xi_prefetch(EL, ENER)) { xiv = s_xi_lane[i * 8]; }
+            if (xi_in_lds(EL) && !XIPF) { xiv = s_xi_lane[i * 8]; }
             pair_interaction<EL, ENER, PRUNE, VDWC, VMOD, PLAIN>(a, xiv, xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, vc,
                                                  fix[i], fiy[i], fiz[i], fjx, fjy, fjz, acc, any);
             if (PRUNE && !any) { imask &= ~bit; }
