@@ -668,7 +668,14 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         }
     }
     // lj_per_pair: the LJ entry of a pair is read when the pair is computed (2 live registers instead of 16)
-    const char *crow = ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER));
+    // (the row's LDS address is pinned in a register: left alone the compiler re-adds lane base and row offset in front
+    // of every pair's read)
+    typedef const char __attribute__((address_space(3))) *lds_cptr_t;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef const f32x2_t __attribute__((address_space(3))) *lds_f2ptr_t;
+    unsigned crow_addr = (unsigned)(unsigned long long)(lds_cptr_t)(ljt_lane + __umul24((unsigned)s.t, (unsigned)ljt_row_bytes(VMOD, ENER)));
+    if (CPAIR) { __asm__ volatile("" : "+v"(crow_addr)); }
+    const lds_cptr_t crow = (lds_cptr_t)(unsigned long long)crow_addr;
     // i-atoms from LDS (xi_in_lds), xi_prefetch: the row of pair i + 1 is requested at the head of pair i, outside the test of pair
     // i + 1's mask bit -- as a volatile access, which the compiler neither sinks into the conditional body (where its
     // whole latency stood between the branch and the first subtraction) nor splits into a 12- and a 4-byte read (8 + 2
@@ -693,7 +700,7 @@ __device__ __forceinline__ void jcluster(const nbx_kernel_view_t &a, const float
         {
             const bool diag = !PLAIN && central && (cj == sci * 8 + i);
             bool       any  = true;
-            if (CPAIR) { c[i] = *reinterpret_cast<const float2 *>(crow + 8 * i); cg[i] = 0.0f; }
+            if (CPAIR) { const f32x2_t v = *(lds_f2ptr_t)(crow + 8 * i); c[i] = make_float2(v.x, v.y); cg[i] = 0.0f; }
             // Ewald flavours: the i-atoms stay in LDS and are read per pair (xi_in_lds)
             if (xi_in_lds(EL) && !XIPF) { xiv = s_xi_lane[i * 8]; }
             pair_interaction<EL, ENER, PRUNE, VDWC, VMOD, PLAIN>(a, xiv, xj, c[i], cg[i], wexcl, JM * 8 + i, !diag || tidxj > tidxi, vc,
