@@ -915,7 +915,7 @@ __global__ void k_sort_keys(int nsci, const nbx_sci_t *__restrict__ sci, const n
 template <bool COUNT, bool PAIRS>
 __global__ void __launch_bounds__(64)
 k_sort_sci(int nsci, int nwaves, int m, int kmax, const nbx_sci_t *__restrict__ sci, const nbx_cj4_t *__restrict__ cj4, int *__restrict__ hist,
-           const int *__restrict__ first, nbx_sci_t *__restrict__ sci_out)
+           const int *__restrict__ first, nbx_sci_t *__restrict__ sci_out, unsigned *__restrict__ keybuf)
 {
     const int  w    = blockIdx.x;
     const int  lane = threadIdx.x;
@@ -923,7 +923,14 @@ k_sort_sci(int nsci, int nwaves, int m, int kmax, const nbx_sci_t *__restrict__ 
     const bool have = i < nsci;
     nbx_sci_t  e;
     if (have) { e = sci[i]; }
-    const int key = have ? (PAIRS ? sci_pair_key(e, cj4, m) : sci_sort_key(e, m)) : -1;
+    // (the pair key walks the entry's groups: the counting pass keeps it for the pass that moves the entries)
+    int key = -1;
+    if (have)
+    {
+        if (!PAIRS) { key = sci_sort_key(e, m); }
+        else if (COUNT) { key = sci_pair_key(e, cj4, m); keybuf[i] = (unsigned)key; }
+        else { key = (int)keybuf[i]; }
+    }
     if (COUNT)
     {
         // lane k counts key k
@@ -1392,20 +1399,20 @@ int nbx_search_make_pairlist(nbx_search *s, hipStream_t st, int iloc, int nzp, c
             if (pair_key)
             {
                 hipLaunchKernelGGL((k_sort_sci<true, true>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, NBX_SCI_PAIR_KEYS - 1, src, s->cj4.p,
-                                   s->sort_hist.p, (const int *)nullptr, (nbx_sci_t *)nullptr);
+                                   s->sort_hist.p, (const int *)nullptr, (nbx_sci_t *)nullptr, s->skey_in.p);
                 S_TRY(hipGetLastError());
                 S_TRY(nbx_prim_exclusive_sum(s->tmp, s->sort_hist.p, s->sort_first.p, (int)nh2, st));
                 hipLaunchKernelGGL((k_sort_sci<false, true>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, NBX_SCI_PAIR_KEYS - 1, src, s->cj4.p,
-                                   (int *)nullptr, s->sort_first.p, dst);
+                                   (int *)nullptr, s->sort_first.p, dst, s->skey_in.p);
                 S_TRY(hipGetLastError());
                 src = s->sci_b.p; dst = s->sci_a.p;
             }
             hipLaunchKernelGGL((k_sort_sci<true, false>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, m, src, s->cj4.p, s->sort_hist.p,
-                               (const int *)nullptr, (nbx_sci_t *)nullptr);
+                               (const int *)nullptr, (nbx_sci_t *)nullptr, (unsigned *)nullptr);
             S_TRY(hipGetLastError());
             S_TRY(nbx_prim_exclusive_sum(s->tmp, s->sort_hist.p, s->sort_first.p, (int)nh, st));
             hipLaunchKernelGGL((k_sort_sci<false, false>), dim3(nwaves), dim3(64), 0, st, nsci, nwaves, m, m, src, s->cj4.p, (int *)nullptr,
-                               s->sort_first.p, dst);
+                               s->sort_first.p, dst, (unsigned *)nullptr);
             S_TRY(hipGetLastError());
             sci_final = dst;
         }
