@@ -323,6 +323,85 @@ def test_copy_kernels_move_the_same_bytes_as_the_copy_engine(nb):
             nb.lib.nbnxn_hip_pfree(ptr)
 
 
+def test_two_locality_sequence_with_host_arrays_on_a_two_stream_handle():
+    """The reference's step with domain decomposition (sim_util.c:1007-1147, 1385-1428): launch_kernel LOCAL then NONLOCAL with the
+    host xq (each copies its own atom range in), launch_cpyback NONLOCAL then LOCAL (each copies its own range of f out; the
+    local one waits for the non-local kernel, nbnxn_cuda.cu:483-503), wait NONLOCAL, wait LOCAL -- on a two-stream handle,
+    with pinned arrays (copy kernels, the local copy-back folding the slots) and with pageable ones (copy engine).  The
+    entries of one list split into those among the first half of the atoms ("local") and the rest: the two launches together
+    must give the whole list's forces and energies; each copy must touch its own range only."""
+    import ctypes as C
+    import torch
+    from gromacs_cosmo_amd.dd import _DevArray
+    from gromacs_cosmo_amd.host import PairList
+    p, ip, d = load_small("spce3240_ewald09")
+    one = g.gpu.NbnxnHip(0)
+    _upload(one, p, ip)
+    f_ref, e_ref = one.compute(p.xq, abi.FORCE_VIRIAL)
+    one.close()
+    nb = g.gpu.NbnxnHip(0, local_and_nonlocal=True)
+    held = []
+
+    def pinned(nfloat):
+        ptr = C.c_void_p()
+        nb.lib.nbnxn_hip_pmalloc(C.byref(ptr), 4 * nfloat)
+        assert ptr.value
+        held.append(ptr)
+        return np.frombuffer((C.c_char * (4 * nfloat)).from_address(ptr.value), dtype=np.float32)
+
+    n = p.natoms
+    nl = (n // 2) // 64 * 64
+    try:
+        nb.init_const(ip, p.ntype, p.nbfp)
+        nb.init_atomdata(n, nl, p.ntype, p.type)
+        nb.upload_shiftvec(p.shift_vec)
+        # local list: the entries that touch atoms below nl only (what a local list is: the non-local copy-back does not wait
+        # for the local kernel); everything else is "non-local" work, which may add to local atoms as well
+        im = (p.pl.cj4["imei"]["imask"][:, 0] | p.pl.cj4["imei"]["imask"][:, 1]).astype(np.uint32)
+        live = np.stack([((im >> (8 * k)) & 0xff) != 0 for k in range(4)], axis=1)
+        gmax = np.where(live, p.pl.cj4["cj"], -1).max(axis=1)
+        local = np.array([e["sci"] * 64 + 64 <= nl and gmax[e["cj4_ind_start"]:e["cj4_ind_end"]].max() * 8 + 8 <= nl for e in p.pl.sci])
+        assert 0.1 * p.pl.nsci < local.sum() < 0.9 * p.pl.nsci
+        nb.init_pairlist(PairList(np.ascontiguousarray(p.pl.sci[local]), p.pl.cj4, p.pl.excl, 0, ip.rlist), abi.LOCAL)
+        nb.init_pairlist(PairList(np.ascontiguousarray(p.pl.sci[~local]), p.pl.cj4, p.pl.excl, 0, ip.rlist), abi.NONLOCAL)
+        for kind in ("pinned", "pageable"):
+            xq_h = pinned(4 * n).reshape(n, 4) if kind == "pinned" else np.empty((n, 4), np.float32)
+            f_h = pinned(3 * n).reshape(n, 3) if kind == "pinned" else np.empty((n, 3), np.float32)
+            xq_h[:] = p.xq
+            # the coordinate copies: a device array of zeros, then the two launches (the forces of THIS pass are meaningless)
+            nb.upload_xq(np.zeros((n, 4), np.float32), abi.LOCAL)
+            nb.upload_xq(np.zeros((n, 4), np.float32), abi.NONLOCAL)
+            d_xq, _, _ = nb.device_buffers()
+            xq_t = torch.as_tensor(_DevArray(d_xq, (n, 4)), device="cuda:0")
+            nb.clear_outputs(0)
+            nb.launch_kernel(xq_h, 0, abi.LOCAL)
+            torch.cuda.synchronize()
+            got = xq_t.cpu().numpy()
+            assert np.array_equal(got[:nl], p.xq[:nl]) and not got[nl:].any()
+            nb.launch_kernel(xq_h, 0, abi.NONLOCAL)
+            torch.cuda.synchronize()
+            assert np.array_equal(xq_t.cpu().numpy(), p.xq)
+            nb.wait_gpu(0, abi.NONLOCAL); nb.wait_gpu(0, abi.LOCAL)
+            # the step
+            for rep in range(2):
+                e_lj, e_el, fsh = np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros((abi.SHIFTS, 3), np.float32)
+                f_h[:] = 7.0
+                nb.clear_outputs(abi.FORCE_VIRIAL)
+                nb.launch_kernel(xq_h, abi.FORCE_VIRIAL, abi.LOCAL)
+                nb.launch_kernel(xq_h, abi.FORCE_VIRIAL, abi.NONLOCAL)
+                nb.launch_cpyback(f_h, abi.FORCE_VIRIAL, abi.NONLOCAL)
+                nb.wait_gpu(abi.FORCE_VIRIAL, abi.NONLOCAL, e_lj, e_el, fsh)
+                assert (f_h[:nl] == 7.0).all() and not (f_h[nl:] == 7.0).all()      # the non-local range only, so far
+                nb.launch_cpyback(f_h, abi.FORCE_VIRIAL, abi.LOCAL)
+                nb.wait_gpu(abi.FORCE_VIRIAL, abi.LOCAL, e_lj, e_el, fsh)
+                assert relrms(f_h, f_ref) < 2e-6
+                assert abs(e_lj[0] - e_ref[0]) < 1e-6 * abs(e_ref[0]) and abs(e_el[0] - e_ref[1]) < 1e-6 * abs(e_ref[1])
+                assert np.abs(fsh - e_ref[2]).max() < 1e-5 * np.abs(e_ref[2]).max()
+            del xq_h, f_h
+    finally:
+        nb.close()
+
+
 @pytest.mark.parametrize("model", ["spc", "spce"])
 def test_config4_size_properties(nb, model):
     """BASELINE config 4 size (13x13x14 tiles, 1,533,168 atoms, >1e9 pair slots) on one GPU.  The
