@@ -10,6 +10,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vecto
 for el in 0 1 2; do
     X="$*"
     if [ $el -eq 2 ]; then X="${X//-DNBX_TIMELINE/}"; fi      # the timeline symbols exist once per electrostatics family
+    if [ $el -ne 0 ]; then X="$X -mllvm -amdgpu-sched-strategy=max-ilp"; fi      # as the Makefile builds the Ewald units
     hipcc $F $X -DNBX_UNIT_EL=$el -c nbnxn_kernel.hip -o ../lib/dbg/k_${name}_el$el.o &
 done
 wait
