@@ -90,9 +90,17 @@ __device__ __forceinline__ nbx_f32x4 lds_load_f32x4_volatile(const float4 *p)
 #ifndef NBX_XI_PREFETCH
 #define NBX_XI_PREFETCH 2    // i-atoms in LDS: the next pair's row is requested a pair ahead, unconditionally: 0 never, 1 always,
 #endif                       // 2 where it was measured to pay (reaction field; Ewald force-only: -2 %; Ewald with energies: +1 %)
+#ifndef NBX_JAHEAD3
+#define NBX_JAHEAD3 2    // j-atoms requested three j-clusters ahead instead of one: 0 never, 1 always, 2 reaction field force-only
+#endif
 #ifndef NBX_KERNEL_WAVES_EW
 #define NBX_KERNEL_WAVES_EW 5    // waves per SIMD the flavours with their i-atoms in LDS are compiled for (5 needs <= 96 registers)
 #endif
+#if NBX_JAHEAD3 && !NBX_HDR2
+#error "NBX_JAHEAD3 needs the next group's header at the top of the iteration (NBX_HDR2)"
+#endif
+// (not with the LJ-PME grid column: two registers would spill)
+constexpr bool j_ahead3(int el, bool ener, int vmod) { return NBX_JAHEAD3 == 1 || (NBX_JAHEAD3 == 2 && el == NBX_EL_RF && !ener && vmod != 3); }
 constexpr bool xi_in_lds(int el) { return NBX_XI_LDS == 1 || (NBX_XI_LDS == 2 && el != NBX_EL_RF); }
 // Per-pair LJ entries (lj_per_pair): instead of the eight entries of a j-cluster fetched ahead into 16 registers, each
 // pair reads its own 8-byte entry when it is computed: 14 registers fewer.  Measured (profiles/r3_r_cpair_ab.txt): Ewald F
@@ -864,6 +872,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
     if (e.cj4_ind_start < e.cj4_ind_end) { load_jraw(a, e.cj4_ind_start, raw0); }
     decode_jhdr(a, raw0, lane, central, sci, cur);
     load_jslot(js, cur.cj[0], sa);
+    constexpr bool JA3 = j_ahead3(EL, ENER, VMOD);
+    nbx_jslot_t    sc, sd;
+    if (JA3)
+    {
+        load_jslot(js, cur.cj[1], sb);
+        load_jslot(js, cur.cj[2], sc);
+    }
 
     // Ewald: the scaled coordinates are x' = fma(x, beta, C) with C = -fl(beta * o), o the entry's first (shifted)
     // i-atom.  The product is exact inside the fma and C is the SAME number for every i- and j-atom of the entry, so
@@ -1027,19 +1042,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
         if (j4 + 1 < e.cj4_ind_end) { load_jhdr(a, j4 + 1, lane, nxt); }
 #define NBX_ITER_TAIL
 #endif
+    // j-atoms are requested one j-cluster ahead (two rolling register sets) or, where it was measured to pay (j_ahead3: the
+    // reaction-field force-only kernels, -1.4 %; Ewald and the energy kernels 0 ... +0.5 %), three ahead (four sets)
+#define NBX_GROUP_BODY(PLAIN)                                                                              \
+        if (JA3)                                                                                           \
+        {                                                                                                  \
+            load_jslot(js, cur.cj[3], sd);                                                                 \
+            NBX_JCLUSTER_P(0, sa, PLAIN);                                                                  \
+            load_jslot(js, nxt.cj[0], sa);                                                                 \
+            NBX_JCLUSTER_P(1, sb, PLAIN);                                                                  \
+            load_jslot(js, nxt.cj[1], sb);                                                                 \
+            NBX_JCLUSTER_P(2, sc, PLAIN);                                                                  \
+            load_jslot(js, nxt.cj[2], sc);                                                                 \
+            NBX_JCLUSTER_P(3, sd, PLAIN);                                                                  \
+        }                                                                                                  \
+        else                                                                                               \
+        {                                                                                                  \
+            load_jslot(js, cur.cj[1], sb);                                                                 \
+            NBX_JCLUSTER_P(0, sa, PLAIN);                                                                  \
+            load_jslot(js, cur.cj[2], sa);                                                                 \
+            NBX_JCLUSTER_P(1, sb, PLAIN);                                                                  \
+            load_jslot(js, cur.cj[3], sb);                                                                 \
+            NBX_JCLUSTER_P(2, sa, PLAIN);                                                                  \
+            load_jslot(js, nxt.cj[0], sa);                                                                 \
+            NBX_JCLUSTER_P(3, sb, PLAIN);                                                                  \
+        }
 #define NBX_ITER(PLAIN)                                                                                    \
     {                                                                                                      \
         nbx_jhdr_t nxt;                                                                                    \
         NBX_ITER_HEAD                                                                                      \
         unsigned imask = cur.imask;                                                                        \
-        load_jslot(js, cur.cj[1], sb);                                                                     \
-        NBX_JCLUSTER_P(0, sa, PLAIN);                                                                      \
-        load_jslot(js, cur.cj[2], sa);                                                                     \
-        NBX_JCLUSTER_P(1, sb, PLAIN);                                                                      \
-        load_jslot(js, cur.cj[3], sb);                                                                     \
-        NBX_JCLUSTER_P(2, sa, PLAIN);                                                                      \
-        load_jslot(js, nxt.cj[0], sa);                                                                     \
-        NBX_JCLUSTER_P(3, sb, PLAIN);                                                                      \
+        NBX_GROUP_BODY(PLAIN)                                                                              \
         if (PRUNE)                                                                                         \
         {                                                                                                  \
             if (lane == 0)                                                                                 \
@@ -1066,6 +1099,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kernel_
 #endif
 #undef NBX_ITER
 #undef NBX_ITER_HEAD
+#undef NBX_GROUP_BODY
 #undef NBX_ITER_TAIL
 #undef NBX_JCLUSTER_P
     if (nfj > 0) { flush_fj(a.f, s_fj, cjs, nfj, lane); }
